@@ -1,0 +1,115 @@
+/*
+ * ldsr_hip.h -- C ABI of libldsr_hip.so, the MI355X (gfx950) engine for ldsr's
+ * EM/Kalman restart path.  Plain pointers and sizes only; no torch / Rcpp types.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *
+ *   ldsr_em_batch            the whole fan-out  foreach(theta0 = init) %dopar% LDS_EM(...)
+ *                            of R/LDS_reconstruction.R:46, i.e. n_cells calls of
+ *                            _ldsr_LDS_EM (src/RcppExports.cpp:40-53 -> src/EM.cpp:245-280),
+ *                            batched over restarts and over series / CV folds
+ *   ldsr_em_batch_device     same, operands already resident in HBM (bench + torch callers)
+ *   ldsr_smooth_batch        _ldsr_Kalman_smoother (src/RcppExports.cpp:11-24 ->
+ *                            src/EM.cpp:22-131), one E-step per (series, theta) cell;
+ *                            also yields the winner's `fit` list of LDS_EM (src/EM.cpp:276-279)
+ *   ldsr_mstep_batch         _ldsr_Mstep (src/RcppExports.cpp:26-38 -> src/EM.cpp:139-229)
+ *   ldsr_propagate_batch     _ldsr_propagate (src/RcppExports.cpp:56-69 -> src/EM.cpp:295-356)
+ *   ldsr_select_restart      the argmax-with-C>0 rule of R/LDS_reconstruction.R:50-58
+ *
+ * Data conventions (identical to the bytes R hands to .Call):
+ *   y      [n_series][T]        double, NaN / NA_real_ = missing
+ *   u      [n_series][T][p]     double; an R p x T matrix is column-major, i.e. exactly
+ *                               this time-major layout (u[t*p + k]).  NULL = input absent
+ *                               (the reference's 1x1 `matrix(0)` sentinel, src/EM.cpp:71)
+ *   v      [n_series][T][q]     likewise (src/EM.cpp:77)
+ *   shared_uv != 0              u and v hold ONE series ([T][p], [T][q]) shared by every
+ *                               y series (cvLDS folds: same inputs, different NA masks,
+ *                               R/LDS_reconstruction.R:274)
+ *   theta  [n_cells][6+p+q]     packed  A, B[p], C, D[q], Q, R, mu1, V1  (list order of
+ *                               src/EM.cpp:221-228).  With u (v) absent p (q) is 1, the
+ *                               B (D) slot is ignored on input and returned as 0, as
+ *                               B.zeros(1, p) at src/EM.cpp:186 (:154)
+ *   cell_offsets [n_series+1]   HOST array: cells [cell_offsets[s], cell_offsets[s+1]) are
+ *                               the restarts of series s
+ *
+ * Limits of this build: 1 <= p, q <= 8 (every BASELINE config and the reference's tests;
+ * larger returns LDSR_EUNSUPPORTED), T >= 2, niter >= 2 (the reference indexes lik[1]
+ * unconditionally, src/EM.cpp:256).
+ *
+ * Every function returns LDSR_OK (0) or an error code; ldsr_last_error() gives the
+ * message of the calling thread's last failure.  Nothing is retained between calls
+ * except a per-device workspace cache freed by ldsr_shutdown().
+ */
+#ifndef LDSR_HIP_H
+#define LDSR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDSR_OK 0
+#define LDSR_EINVAL 1        /* bad argument */
+#define LDSR_EUNSUPPORTED 2  /* p or q above the compiled limit */
+#define LDSR_EHIP 3          /* a HIP runtime call failed (no device, OOM, launch error) */
+
+/* per-cell status words */
+#define LDSR_CELL_OK 0
+#define LDSR_CELL_NONFINITE 1 /* final lik is NaN/Inf (tolerated by the reference's selection, na.rm) */
+#define LDSR_CELL_SINGULAR 2  /* Svv or Tuu of the series is singular: arma::inv would throw */
+
+/* algorithm selector */
+#define LDSR_ALGO_AUTO 0
+#define LDSR_ALGO_SERIAL 1 /* one thread per cell, sequential in time (any T) */
+#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 64*32) */
+
+const char *ldsr_last_error(void);
+const char *ldsr_version(void);
+int ldsr_device_count(void);
+void ldsr_shutdown(void);
+
+/* Batched LDS_EM.  Host pointers; copies in, runs on `device`, copies out.
+ * liks may be NULL; otherwise [n_cells][niter], entries beyond n_iter[c] are NaN. */
+int ldsr_em_batch(int device, int n_series, int T, int p, int q, const double *y,
+                  const double *u, const double *v, int shared_uv, const int *cell_offsets,
+                  const double *theta0, int niter, double tol, int algo,
+                  double *theta, double *lik, int *n_iter, int *status, double *liks);
+
+/* Same with DEVICE pointers (cell_offsets stays a host array).  Asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream).  workspace: device buffer of at
+ * least ldsr_em_workspace_bytes(...) bytes, 256-byte aligned. */
+size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int n_cells, int algo);
+int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, int q,
+                         const double *d_y, const double *d_u, const double *d_v,
+                         int shared_uv, const int *cell_offsets, const double *d_theta0,
+                         int niter, double tol, int algo, double *d_theta, double *d_lik,
+                         int *d_n_iter, int *d_status, double *d_liks, void *d_workspace,
+                         size_t workspace_bytes);
+
+/* Batched Kalman_smoother: one E-step for each cell's theta.  Host pointers.
+ * X, Y, V, J: [n_cells][T] (any may be NULL); lik: [n_cells].  stdlik as src/EM.cpp:124. */
+int ldsr_smooth_batch(int device, int n_series, int T, int p, int q, const double *y,
+                      const double *u, const double *v, int shared_uv,
+                      const int *cell_offsets, const double *theta, int stdlik, double *X,
+                      double *Y, double *V, double *J, double *lik);
+
+/* Batched Mstep: fit (X, V, J: [n_cells][T]) -> theta [n_cells][6+p+q].  Host pointers. */
+int ldsr_mstep_batch(int device, int n_series, int T, int p, int q, const double *y,
+                     const double *u, const double *v, int shared_uv,
+                     const int *cell_offsets, const double *X, const double *V,
+                     const double *J, double *theta, int *status);
+
+/* Batched propagate (no measurement update).  X, Y, V: [n_cells][T]; lik [n_cells]. */
+int ldsr_propagate_batch(int device, int n_series, int T, int p, int q, const double *y,
+                         const double *u, const double *v, int shared_uv,
+                         const int *cell_offsets, const double *theta, int stdlik, double *X,
+                         double *Y, double *V, double *lik);
+
+/* Restart selection on the host: index of the winning cell among n, or -1. */
+int ldsr_select_restart(int n, const double *lik, const double *theta, int p, int q);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

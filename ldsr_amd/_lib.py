@@ -1,0 +1,62 @@
+"""ctypes loader for libldsr_hip.so (built in-tree by __graft_entry__.build() or
+`make -C ldsr_amd/csrc`).  There is NO CPU fallback: if the library is missing or does not
+export a symbol of include/ldsr_hip.h, importing callers fail loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libldsr_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ldsr_hip.h one to one
+SIGNATURES = {
+    "ldsr_last_error": (C.c_char_p, []),
+    "ldsr_version": (C.c_char_p, []),
+    "ldsr_device_count": (C.c_int, []),
+    "ldsr_shutdown": (None, []),
+    "ldsr_em_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _ip,
+                                _ip, _dp]),
+    "ldsr_em_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldsr_em_batch_device": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                       _vp, C.c_int, _ip, _vp, C.c_int, C.c_double, C.c_int, _vp,
+                                       _vp, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "ldsr_smooth_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                    C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "ldsr_mstep_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                   C.c_int, _ip, _dp, _dp, _dp, _dp, _ip]),
+    "ldsr_propagate_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                       C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "ldsr_select_restart": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int]),
+}
+
+_LIB = None
+
+
+class LdsrError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise LdsrError(
+                "libldsr_hip.so not found at %s -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C ldsr_amd/csrc`; there is no CPU "
+                "fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise LdsrError("libldsr_hip error %d: %s" % (rc, lib().ldsr_last_error().decode()))

@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's operator interface for the EM/Kalman path.
+
+Same names, argument meaning and return shape as the R / Rcpp surface it replaces
+(paths under /root/reference):
+
+    make_init        R/LDS_reconstruction.R:14-30
+    LDS_EM_restart   R/LDS_reconstruction.R:42-62   (the foreach fan-out + selection)
+    LDS_EM           R/RcppExports.R:41-43  -> src/EM.cpp:245-280
+    Kalman_smoother  R/RcppExports.R:15-17  -> src/EM.cpp:22-131
+    Mstep            R/RcppExports.R:24-26  -> src/EM.cpp:139-229
+    propagate        R/RcppExports.R:57-59  -> src/EM.cpp:295-356
+
+Everything numeric runs on the GPU through the C ABI of include/ldsr_hip.h (ctypes); this
+module only marshals.  A `theta` is a dict with the reference's list names
+(A, B, C, D, Q, R, mu1, V1; B is 1 x p, D is 1 x q); packed arrays [A, B.., C, D.., Q, R,
+mu1, V1] are accepted wherever a theta is.  u / v are p x T and q x T arrays as in R, or
+None for an absent input (the reference's `matrix(0)` sentinel).  y is length T with NaN
+for missing values.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .synth import make_init_packed
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+ALGO_AUTO, ALGO_SERIAL, ALGO_SCAN = 0, 1, 2
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def pack_theta(theta, p, q):
+    if isinstance(theta, dict):
+        out = np.concatenate([
+            np.ravel(theta["A"]), np.ravel(theta["B"]), np.ravel(theta["C"]), np.ravel(theta["D"]),
+            np.ravel(theta["Q"]), np.ravel(theta["R"]), np.ravel(theta["mu1"]),
+            np.ravel(theta["V1"])]).astype(np.float64)
+    else:
+        out = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1)
+    if out.size != 6 + p + q:
+        raise ValueError("theta has %d entries, expected 6+p+q = %d" % (out.size, 6 + p + q))
+    return out
+
+
+def unpack_theta(th, p, q):
+    th = np.asarray(th, dtype=np.float64)
+    return {"A": th[0:1].reshape(1, 1).copy(), "B": th[1:1 + p].reshape(1, p).copy(),
+            "C": th[1 + p:2 + p].reshape(1, 1).copy(),
+            "D": th[2 + p:2 + p + q].reshape(1, q).copy(),
+            "Q": th[2 + p + q:3 + p + q].reshape(1, 1).copy(),
+            "R": th[3 + p + q:4 + p + q].reshape(1, 1).copy(),
+            "mu1": th[4 + p + q:5 + p + q].reshape(1, 1).copy(),
+            "V1": th[5 + p + q:6 + p + q].reshape(1, 1).copy()}
+
+
+def make_init(p, q, num_restarts, seed=None):
+    """List of `num_restarts` random initial thetas with the reference's distribution.
+    (R's Mersenne-Twister stream is not reproduced; pass an explicit `init` list made in R to
+    replay an R session.)"""
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0])
+    packed = make_init_packed(p, q, num_restarts, seed=seed)
+    return [unpack_theta(t, p, q) for t in packed]
+
+
+def _series(y, u, v):
+    """Marshal one or several series.  y: [T] or [S,T]; u: [p,T] or [S,p,T] or None."""
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim == 2 and y.shape[0] == 1:
+        y = y[0]
+    multi = y.ndim == 2
+    Y = np.ascontiguousarray(y if multi else y[None, :])
+    S, T = Y.shape
+
+    def prep(a, name):
+        if a is None:
+            return None, 1, True
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 2:
+            if a.shape[1] != T:
+                raise ValueError("%s must have T = %d columns" % (name, T))
+            return np.ascontiguousarray(a.T)[None], a.shape[0], True     # [1,T,k] shared
+        if a.ndim == 3:
+            if a.shape[0] != S or a.shape[2] != T:
+                raise ValueError("%s must be [S, k, T]" % name)
+            return np.ascontiguousarray(np.transpose(a, (0, 2, 1))), a.shape[1], False
+        raise ValueError("%s must be 2-D (k x T) or 3-D (S x k x T)" % name)
+
+    U, p, us = prep(u, "u")
+    V, q, vs = prep(v, "v")
+    shared = 1 if (us and vs) else 0
+    if not shared:      # mixed: replicate the shared one
+        if U is not None and us:
+            U = np.ascontiguousarray(np.repeat(U, S, axis=0))
+        if V is not None and vs:
+            V = np.ascontiguousarray(np.repeat(V, S, axis=0))
+    if S == 1:
+        shared = 0
+    return Y, U, V, S, T, p, q, shared
+
+
+def em_batch(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, device=0, algo=ALGO_AUTO,
+             return_liks=False):
+    """All cells in one launch.  theta0: packed [n_cells, 6+p+q].  cell_offsets: [S+1]
+    (default: every cell belongs to series 0).  Returns dict of arrays theta, lik, n_iter,
+    status (and liks [n_cells, niter], NaN padded)."""
+    Y, U, V, S, T, p, q, shared = _series(y, u, v)
+    theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+    if theta0.ndim != 2 or theta0.shape[1] != 6 + p + q:
+        raise ValueError("theta0 must be [n_cells, %d]" % (6 + p + q))
+    n = theta0.shape[0]
+    if cell_offsets is None:
+        if S != 1:
+            raise ValueError("cell_offsets is required with several series")
+        cell_offsets = [0, n]
+    off = np.ascontiguousarray(cell_offsets, dtype=np.int32)
+    if off.size != S + 1 or off[-1] != n:
+        raise ValueError("cell_offsets must have S+1 entries ending at n_cells")
+    theta = np.empty_like(theta0)
+    lik = np.empty(n)
+    n_iter = np.empty(n, dtype=np.int32)
+    status = np.empty(n, dtype=np.int32)
+    liks = np.empty((n, niter)) if return_liks else None
+    L = _lib.lib()
+    _lib.check(L.ldsr_em_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off),
+                               _d(theta0), int(niter), float(tol), int(algo), _d(theta), _d(lik),
+                               _i(n_iter), _i(status), _d(liks)))
+    out = {"theta": theta, "lik": lik, "n_iter": n_iter, "status": status}
+    if return_liks:
+        out["liks"] = liks
+    return out
+
+
+def smooth_batch(y, u, v, theta, cell_offsets=None, stdlik=True, device=0, mode="smooth"):
+    Y, U, V, S, T, p, q, shared = _series(y, u, v)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    n = theta.shape[0]
+    if cell_offsets is None:
+        cell_offsets = [0, n]
+    off = np.ascontiguousarray(cell_offsets, dtype=np.int32)
+    X, Yh, Vv, J = (np.empty((n, T)) for _ in range(4))
+    lik = np.empty(n)
+    L = _lib.lib()
+    if mode == "smooth":
+        _lib.check(L.ldsr_smooth_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off),
+                                       _d(theta), int(bool(stdlik)), _d(X), _d(Yh), _d(Vv), _d(J),
+                                       _d(lik)))
+        return {"X": X, "Y": Yh, "V": Vv, "J": J, "lik": lik}
+    _lib.check(L.ldsr_propagate_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off),
+                                      _d(theta), int(bool(stdlik)), _d(X), _d(Yh), _d(Vv), _d(lik)))
+    return {"X": X, "Y": Yh, "V": Vv, "lik": lik}
+
+
+def _dims(u, v):
+    p = 1 if u is None else np.asarray(u).shape[-2]
+    q = 1 if v is None else np.asarray(v).shape[-2]
+    return p, q
+
+
+def Kalman_smoother(y, u, v, theta, stdlik=True, device=0):
+    """-> {"X","Y","V","J": 1 x T arrays, "lik": float}   (src/EM.cpp:126-130)"""
+    p, q = _dims(u, v)
+    r = smooth_batch(y, u, v, pack_theta(theta, p, q)[None, :], stdlik=stdlik, device=device)
+    return {"X": r["X"], "Y": r["Y"], "V": r["V"], "J": r["J"], "lik": float(r["lik"][0])}
+
+
+def propagate(theta, u, v, y, stdlik=True, device=0):
+    """-> {"X","Y","V": 1 x T arrays, "lik": float}   (src/EM.cpp:352-355)"""
+    p, q = _dims(u, v)
+    r = smooth_batch(y, u, v, pack_theta(theta, p, q)[None, :], stdlik=stdlik, device=device,
+                     mode="propagate")
+    return {"X": r["X"], "Y": r["Y"], "V": r["V"], "lik": float(r["lik"][0])}
+
+
+def Mstep(y, u, v, fit, device=0):
+    """fit: result of Kalman_smoother -> theta dict   (src/EM.cpp:221-228)"""
+    Y, U, V, S, T, p, q, shared = _series(y, u, v)
+    X = np.ascontiguousarray(np.asarray(fit["X"], dtype=np.float64).reshape(1, T))
+    Vv = np.ascontiguousarray(np.asarray(fit["V"], dtype=np.float64).reshape(1, T))
+    J = np.ascontiguousarray(np.asarray(fit["J"], dtype=np.float64).reshape(1, T))
+    th = np.empty((1, 6 + p + q))
+    st = np.empty(1, dtype=np.int32)
+    off = np.array([0, 1], dtype=np.int32)
+    L = _lib.lib()
+    _lib.check(L.ldsr_mstep_batch(device, 1, T, p, q, _d(Y), _d(U), _d(V), 0, _i(off), _d(X),
+                                  _d(Vv), _d(J), _d(th), _i(st)))
+    if st[0] == 2:
+        raise _lib.LdsrError("Mstep: matrix is singular")   # arma::inv throws here
+    return unpack_theta(th[0], p, q)
+
+
+def LDS_EM(y, u, v, theta0, niter=1000, tol=1e-5, device=0, algo=ALGO_AUTO):
+    """-> {"theta", "fit", "liks", "lik"}   (src/EM.cpp:276-279)"""
+    p, q = _dims(u, v)
+    r = em_batch(y, u, v, pack_theta(theta0, p, q)[None, :], niter=niter, tol=tol, device=device,
+                 algo=algo, return_liks=True)
+    if r["status"][0] == 2:
+        raise _lib.LdsrError("LDS_EM: matrix is singular")
+    th = r["theta"][0]
+    fit = Kalman_smoother(y, u, v, th, device=device)
+    n_it = int(r["n_iter"][0])
+    return {"theta": unpack_theta(th, p, q), "fit": fit, "liks": r["liks"][0, :n_it].copy(),
+            "lik": float(r["lik"][0])}
+
+
+def select_restart(lik, theta_packed, p, q):
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    th = np.ascontiguousarray(theta_packed, dtype=np.float64)
+    return int(_lib.lib().ldsr_select_restart(lik.size, _d(lik), _d(th), p, q))
+
+
+def LDS_EM_restart(y, u, v, init, niter=1000, tol=1e-5, return_init=True, device=0,
+                   algo=ALGO_AUTO):
+    """One LDS_EM per element of `init`, all in one GPU launch, then the reference's selection
+    (highest likelihood among models with C > 0 if any).  Returns the winning model in LDS_EM's
+    shape (+ "init"), plus "all" = per-restart lik / theta / n_iter / status arrays."""
+    p, q = _dims(u, v)
+    theta0 = np.stack([pack_theta(t, p, q) for t in init])
+    r = em_batch(y, u, v, theta0, niter=niter, tol=tol, device=device, algo=algo, return_liks=True)
+    if np.any(r["status"] == 2):
+        raise _lib.LdsrError("LDS_EM_restart: matrix is singular")
+    k = select_restart(r["lik"], r["theta"], p, q)
+    if k < 0:
+        raise _lib.LdsrError("LDS_EM_restart: no restart produced a finite likelihood")
+    th = r["theta"][k]
+    ans = {"theta": unpack_theta(th, p, q), "fit": Kalman_smoother(y, u, v, th, device=device),
+           "liks": r["liks"][k, :int(r["n_iter"][k])].copy(), "lik": float(r["lik"][k])}
+    if return_init:
+        ans["init"] = init[k]
+    ans["all"] = {"lik": r["lik"], "theta": r["theta"], "n_iter": r["n_iter"],
+                  "status": r["status"], "selected": k}
+    return ans

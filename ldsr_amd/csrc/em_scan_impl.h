@@ -1,0 +1,408 @@
+// em_scan_impl.h -- wave-per-cell, parallel-in-time EM kernel (the fast path, T <= 64*32).
+//
+// One 64-lane wavefront owns one (series, restart) cell for the whole EM loop.  Lane l owns
+// the L consecutive time steps [l*L, l*L+L); all per-step state lives in that lane's
+// registers and nothing but the final theta ever goes to HBM.  The series (y,u,v) is staged
+// once per workgroup into LDS in a chunk-transposed layout [j][lane] so that the 64 lanes of
+// a wave read consecutive 8-byte words (conflict-free ds_read_b64).
+//
+// The reference recursions (/root/reference/src/EM.cpp:70-104) are strictly sequential in t.
+// They are compositions of associative maps, so each E-step is done in three phases per
+// direction:
+//
+//  forward (:70-90)   The joint filter state is carried in projective coordinates
+//                     (n, d, xt) with Vp = n/d, Xp = xt/d.  One time step is LINEAR in them:
+//                         n'  = (A^2 R + Q c^2) n + (Q R) d
+//                         d'  =          c^2  n +     R d
+//                         xt' = (A c e + bu c^2) n + (bu R) d + (A R) xt
+//                     with c = C on observed steps and 0 on missing ones, e = y - D v,
+//                     bu = B u.  (F1) every lane multiplies its L step matrices;
+//                     (scan) a 64-lane inclusive scan composes them; (F2) every lane re-runs
+//                     its L steps serially from its exact entry state with the reference's
+//                     own expressions and keeps J_t, g_t = Xu_t - J_t Xp_{t+1},
+//                     h_t = Vu_t - J_t^2 Vp_{t+1} in registers.
+//  backward (:94-104) Xs_t = J_t Xs_{t+1} + g_t, Vs_t = J_t^2 Vs_{t+1} + h_t are affine maps:
+//                     (B1) compose per lane, (scan) reverse 64-lane scan, (B2) serial re-run
+//                     from the exact entry value, fused with every M-step sum (:151-193).
+//
+// Reassociation changes results at the 1e-15 level (measured against the oracle in
+// tests/test_gpu_parity.py); iteration counts are identical.
+#pragma once
+#include "ldsr_device.h"
+
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (the divide expansion minus its final
+// correction; parity bar is 1e-6 relative).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double uniform_d(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+__device__ __forceinline__ double wave_min(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = fmin(x, __shfl_xor(x, d, 64));
+    return x;
+}
+
+// Structured 3x3 step / composite matrix [[m00 m01 0],[m10 m11 0],[m20 m21 m22]].
+struct PMat {
+    double m00, m01, m10, m11, m20, m21, m22;
+};
+
+// r = a * b  (apply b first, then a)
+__device__ __forceinline__ PMat pmul(const PMat &a, const PMat &b) {
+    PMat r;
+    r.m00 = fma(a.m00, b.m00, a.m01 * b.m10);
+    r.m01 = fma(a.m00, b.m01, a.m01 * b.m11);
+    r.m10 = fma(a.m10, b.m00, a.m11 * b.m10);
+    r.m11 = fma(a.m10, b.m01, a.m11 * b.m11);
+    r.m20 = fma(a.m20, b.m00, fma(a.m21, b.m10, a.m22 * b.m20));
+    r.m21 = fma(a.m20, b.m01, fma(a.m21, b.m11, a.m22 * b.m21));
+    r.m22 = a.m22 * b.m22;
+    return r;
+}
+
+// Exact power-of-two rescale so that the 2x2 block has max magnitude in [1,2).
+__device__ __forceinline__ void prenorm(PMat &m) {
+    const double mx = fmax(fmax(fabs(m.m00), fabs(m.m01)), fmax(fabs(m.m10), fabs(m.m11)));
+    const int e = 1 - __builtin_amdgcn_frexp_exp(mx);
+    m.m00 = __builtin_amdgcn_ldexp(m.m00, e);
+    m.m01 = __builtin_amdgcn_ldexp(m.m01, e);
+    m.m10 = __builtin_amdgcn_ldexp(m.m10, e);
+    m.m11 = __builtin_amdgcn_ldexp(m.m11, e);
+    m.m20 = __builtin_amdgcn_ldexp(m.m20, e);
+    m.m21 = __builtin_amdgcn_ldexp(m.m21, e);
+    m.m22 = __builtin_amdgcn_ldexp(m.m22, e);
+}
+
+__device__ __forceinline__ PMat pshfl_up(const PMat &m, int d) {
+    PMat r;
+    r.m00 = __shfl_up(m.m00, d, 64);
+    r.m01 = __shfl_up(m.m01, d, 64);
+    r.m10 = __shfl_up(m.m10, d, 64);
+    r.m11 = __shfl_up(m.m11, d, 64);
+    r.m20 = __shfl_up(m.m20, d, 64);
+    r.m21 = __shfl_up(m.m21, d, 64);
+    r.m22 = __shfl_up(m.m22, d, 64);
+    return r;
+}
+
+template <int PP, int QQ, int L>
+__global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams prm) {
+    extern __shared__ double smem[];
+    // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
+    double *ys = smem;                  // [L][64]       y, 0 where missing / beyond T
+    double *us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t >= T-1
+    double *vs = us + 64 * L * PP;      // [L][QQ][64]   v_t
+
+    const int b = blockIdx.x;
+    const int s = prm.blk_series[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
+    const int T = prm.T;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    {
+        const double *gy = prm.yp + (long)s * T;
+        const double *gu = prm.up + (long)s * prm.u_stride;
+        const double *gv = prm.vp + (long)s * prm.v_stride;
+        for (int i = threadIdx.x; i < 64 * L; i += blockDim.x) {
+            const int j = i >> 6, l = i & 63, t = l * L + j;
+            double yv = (t < T) ? gy[t] : 0.0;
+            ys[i] = isfinite(yv) ? yv : 0.0;
+        }
+        for (int i = threadIdx.x; i < 64 * L * PP; i += blockDim.x) {
+            const int l = i & 63, jk = i >> 6, j = jk / PP, k = jk - j * PP, t = l * L + j;
+            us[i] = (t < T) ? gu[(long)t * PP + k] : 0.0;
+        }
+        for (int i = threadIdx.x; i < 64 * L * QQ; i += blockDim.x) {
+            const int l = i & 63, jk = i >> 6, j = jk / QQ, k = jk - j * QQ, t = l * L + j;
+            vs[i] = (t < T) ? gv[(long)t * QQ + k] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (wave >= nc) return;   // whole wave leaves; no barrier follows
+
+    const int cell = c0 + wave;
+    const int P = 6 + prm.p + prm.q;
+    const SeriesConst *__restrict__ sc = prm.sc + s;
+    const int n_obs = sc->n_obs;
+    const int t0 = lane * L;
+    const int nvalid = min(max(T - t0, 0), L);
+    const int lastLane = (T - 1) / L, jLast = (T - 1) - lastLane * L;  // owner of step T-1
+
+    // observation mask of this lane's chunk
+    unsigned obsmask = 0;
+    {
+        const double *gy = prm.yp + (long)s * T;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int t = t0 + j;
+            const double yv = (t < T) ? gy[t] : NAN;
+            if (isfinite(yv)) obsmask |= (1u << j);
+        }
+    }
+
+    Theta<PP, QQ> th;
+    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    if (sc->status != 0) {
+        if (lane == 0) {
+            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+            prm.lik[cell] = NAN;
+            prm.n_iter[cell] = 0;
+            prm.status[cell] = 2;
+            if (prm.liks)
+                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+        }
+        return;
+    }
+
+    double lik = NAN, lik1 = NAN, lik2 = NAN;
+    int it = 0;
+    double Jv[L], gv_[L], hv[L];
+
+    for (;;) {
+        const double A = th.A, C = th.C, Q = th.Q, R = th.R;
+        const double A2 = A * A, C2 = C * C, AR = A * R, AC = A * C, QR = Q * R;
+        const double A2R = A2 * R, alpha = fma(Q, C2, A2R);
+
+        // ------------------------------------------------ F1: compose this lane's step matrices
+        PMat M;
+        M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            if (j < nvalid) {
+                const bool o = (obsmask >> j) & 1u;
+                double e = ys[j * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+                double bu = 0.0;
+#pragma unroll
+                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+                PMat S;
+                S.m00 = o ? alpha : A2R;
+                S.m01 = QR;
+                S.m10 = o ? C2 : 0.0;
+                S.m11 = R;
+                S.m20 = o ? fma(bu, C2, AC * e) : 0.0;
+                S.m21 = bu * R;
+                S.m22 = AR;
+                if (j == 0) M = S; else M = pmul(S, M);
+                if ((j & 7) == 7 && j != L - 1) prenorm(M);
+            }
+        }
+        prenorm(M);
+
+        // ------------------------------------------------ forward scan (inclusive, by lane)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const PMat Pm = pshfl_up(M, d);
+            if (lane >= d) M = pmul(M, Pm);
+            if (d == 4 || d == 32) prenorm(M);
+        }
+        // state after this lane's chunk, then shift by one lane to get the entry state
+        double n_e = fma(M.m00, th.V1, M.m01);
+        double d_e = fma(M.m10, th.V1, M.m11);
+        double x_e = fma(M.m20, th.V1, fma(M.m22, th.mu1, M.m21));
+        n_e = __shfl_up(n_e, 1, 64);
+        d_e = __shfl_up(d_e, 1, 64);
+        x_e = __shfl_up(x_e, 1, 64);
+        double Xp, Vp;
+        {
+            const double rd = fast_rcp(d_e);
+            Vp = (lane == 0) ? th.V1 : n_e * rd;
+            Xp = (lane == 0) ? th.mu1 : x_e * rd;
+        }
+
+        // ------------------------------------------------ F2: serial re-run from the exact entry
+        double likq = 0.0, sprod = 1.0, smin = 1.0;
+        double r0 = fast_rcp(fma(C2, Vp, R));
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            if (j < nvalid) {
+                const bool o = (obsmask >> j) & 1u;
+                double e = ys[j * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+                double bu = 0.0;
+#pragma unroll
+                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+                const double sg = fma(C2, Vp, R);          // Sigma_t  (src/EM.cpp:119)
+                const double r = o ? r0 : 0.0;             // 1/Sigma_t, 0 = "no update" (:82-84)
+                const double sl = o ? sg : 1.0;
+                sprod *= sl;
+                smin = fmin(smin, sl);
+                const double w = Vp * r;
+                const double K = C * w;                    // :86
+                const double Vu = fma(-(C2 * w), Vp, Vp);  // (1 - K C) Vp  :88
+                const double dl = fma(-C, Xp, e);          // y - Yp
+                const double Xu = fma(K, dl, Xp);          // :87
+                likq = fma(dl * r, dl, likq);              // delta/Sigma*delta  :122
+                const double Vp1 = fma(A2, Vu, Q);         // :76
+                const double Xp1 = fma(A, Xu, bu);         // :74
+                const double sg1 = fma(C2, Vp1, R);
+                const double z = fast_rcp(sg1 * Vp1);      // one reciprocal for 1/Vp1 and 1/sg1
+                const double rp = sg1 * z;
+                r0 = Vp1 * z;
+                const double AVu = A * Vu;
+                const double J = AVu * rp;                 // :100 (and :98 for t = T-1)
+                Jv[j] = J;
+                gv_[j] = fma(-J, Xp1, Xu);
+                hv[j] = fma(-J, AVu, Vu);
+                Xp = Xp1;
+                Vp = Vp1;
+            }
+        }
+        // terminal state (Xp_T, Vp_T): Xs_{T-1} = Xu_{T-1} + J_{T-1}(Xp_T - Xp_T)
+        const double XT = readlane_d(Xp, 63), VT = readlane_d(Vp, 63);
+
+        // likelihood (:113-124)
+        {
+            const double lq = wave_sum(likq);
+            const double ld = wave_sum(log(sprod));
+            const double mn = wave_min(smin);
+            lik2 = lik1;
+            lik1 = lik;
+            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (lq + ld)) / n_obs;
+            if (mn < 0.0) lik = NAN;   // log of a negative Sigma in the reference
+        }
+        if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
+        it++;
+        bool stop = it >= prm.niter;
+        if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
+        if (__builtin_amdgcn_readfirstlane((int)stop)) break;
+
+        // ------------------------------------------------ B1: compose the reverse affine maps
+        double Pi = 1.0, G = 0.0, H = 0.0;
+#pragma unroll
+        for (int j = L - 1; j >= 0; j--) {
+            if (j < nvalid) {
+                const double J = Jv[j];
+                G = fma(J, G, gv_[j]);
+                H = fma(J * J, H, hv[j]);
+                Pi *= J;
+            }
+        }
+        // reverse inclusive scan: lane l composes its map after those of lanes > l
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double Pb = __shfl_down(Pi, d, 64);
+            const double Gb = __shfl_down(G, d, 64);
+            const double Hb = __shfl_down(H, d, 64);
+            if (lane + d < 64) {
+                G = fma(Pi, Gb, G);
+                H = fma(Pi * Pi, Hb, H);
+                Pi *= Pb;
+            }
+        }
+        // Xs at the first step of this lane's chunk; the entry for lane l is lane l+1's value
+        double Xn = fma(Pi, XT, G);
+        double Vn = fma(Pi * Pi, VT, H);
+        Xn = __shfl_down(Xn, 1, 64);
+        Vn = __shfl_down(Vn, 1, 64);
+        if (lane == 63) { Xn = XT; Vn = VT; }
+
+        // ------------------------------------------------ B2: serial reverse re-run + M-step sums
+        double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, termLast = 0.0, term = 0.0;
+        double aSxv[QQ], aTx1u[PP], aTux[PP];
+#pragma unroll
+        for (int k = 0; k < QQ; k++) aSxv[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < PP; k++) { aTx1u[k] = 0.0; aTux[k] = 0.0; }
+        double Xs = Xn, Vs = Vn;
+#pragma unroll
+        for (int j = L - 1; j >= 0; j--) {
+            if (j < nvalid) {
+                const bool o = (obsmask >> j) & 1u;
+                const double J = Jv[j];
+                Xs = fma(J, Xn, gv_[j]);        // :101
+                Vs = fma(J * J, Vn, hv[j]);     // :102
+                if (j != jLast || lane != lastLane)   // pairs (t, t+1) exist for t <= T-2 only
+                    aTx1x = fma(Xn, Xs, fma(Vn, J, aTx1x));   // :180
+#pragma unroll
+                for (int k = 0; k < PP; k++) {
+                    const double ut = us[(j * PP + k) * 64 + lane];   // zero at t = T-1
+                    aTx1u[k] = fma(Xn, ut, aTx1u[k]);                 // :190
+                    aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
+                }
+                term = fma(Xs, Xs, Vs);
+                aPall += term;                                        // :181,:183
+                if (j == jLast) termLast = term;
+                const double xo = o ? Xs : 0.0;
+                aSyx = fma(ys[j * 64 + lane], xo, aSyx);              // :151
+                aSxx += o ? term : 0.0;                               // :152
+#pragma unroll
+                for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
+                Xn = Xs;
+                Vn = Vs;
+            }
+        }
+        Sums<PP, QQ> S;
+        S.Syx = wave_sum(aSyx);
+        S.Sxx = wave_sum(aSxx);
+        S.Tx1x = wave_sum(aTx1x);
+        const double Pall = wave_sum(aPall);
+#pragma unroll
+        for (int k = 0; k < QQ; k++) S.Sxv[k] = wave_sum(aSxv[k]);
+#pragma unroll
+        for (int k = 0; k < PP; k++) { S.Tx1u[k] = wave_sum(aTx1u[k]); S.Tux[k] = wave_sum(aTux[k]); }
+        S.X0 = readlane_d(Xs, 0);
+        S.V0 = readlane_d(Vs, 0);
+        S.Txx = Pall - readlane_d(termLast, lastLane);    // t = 0 .. T-2
+        S.Tx1x1 = Pall - readlane_d(term, 0);             // t = 1 .. T-1
+        mstep_update(th, S, sc, T);
+        // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
+        th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
+        th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);
+#pragma unroll
+        for (int k = 0; k < PP; k++) th.B[k] = uniform_d(th.B[k]);
+#pragma unroll
+        for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
+    }
+
+    if (lane == 0) {
+        store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+        if (prm.liks)
+            for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+        prm.lik[cell] = lik;
+        prm.n_iter[cell] = it;
+        prm.status[cell] = isfinite(lik) ? 0 : 1;
+    }
+}
+
+// waves per block so that a CU holds ~8 waves given the LDS image of one series
+static inline int scan_wpb(int L, int PP, int QQ) {
+    const size_t lds = (size_t)64 * L * (1 + PP + QQ) * sizeof(double);
+    const int blocks_per_cu = (int)((160 * 1024) / lds);
+    const int want = (L > 16) ? 4 : 8;       // L = 32 kernels hold one wave per SIMD
+    int wpb = (want + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    if (wpb < 2) wpb = 2;
+    if (L <= 16 && wpb < 4 && lds > 20 * 1024) wpb = 4;
+    const int cap = (L > 16) ? 4 : 8;
+    return wpb > cap ? cap : wpb;
+}
+
+template <int L>
+hipError_t launch_em_scan_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb,
+                            hipStream_t stream);

@@ -1,0 +1,24 @@
+// kernels_scan.hip -- chooses the chunk length L (time steps per lane) of the wave-per-cell
+// scan kernel and dispatches to the per-L translation units (em_scan_L*.hip).
+#include "em_scan_impl.h"
+#include "ldsr_kernels.h"
+
+static int scan_L_for(int T) { return T <= 64 * 4 ? 4 : T <= 64 * 16 ? 16 : T <= 64 * 32 ? 32 : 0; }
+
+bool em_scan_supported(int T, int PP, int QQ) {
+    const int L = scan_L_for(T);
+    if (!L) return false;
+    return (size_t)64 * L * (1 + PP + QQ) * sizeof(double) <= 160 * 1024;
+}
+
+int em_scan_waves_per_block(int T, int PP, int QQ) { return scan_wpb(scan_L_for(T), PP, QQ); }
+
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb,
+                          hipStream_t stream) {
+    switch (scan_L_for(prm.T)) {
+        case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, stream);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,165 @@
+// ldsr_device.h -- device-side types shared by the gfx950 kernels of libldsr_hip.so.
+//
+// Model (reference: /root/reference/src/EM.cpp:20 "one dimensional state and output"):
+//   x_{t+1} = A x_t + B u_t + w_t,  w ~ N(0,Q)         y_t = C x_t + D v_t + e_t,  e ~ N(0,R)
+// p = rows of u, q = rows of v.  Kernels are instantiated on padded sizes PP, QQ in
+// {1,2,4,8}; padded rows of u / v are zero, so they contribute nothing to any sum, and the
+// per-series inverse blocks are padded with identity so the padded B / D entries solve to 0.
+// An absent u (v) is the same thing with p (q) = 1 and an all-zero row, which reproduces
+// the reference's absent-input branches (src/EM.cpp:71-75,172,212-213) exactly.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define LDSR_MAXPQ 8
+
+// Theta-independent statistics of one (series, NA mask): computed once by series_prep_kernel.
+// The reference recomputes Svv, Syv, Tuu on every Mstep call (src/EM.cpp:158-161,193).
+struct SeriesConst {
+    int n_obs;    // number of finite y_t           (src/EM.cpp:113-114,147)
+    int status;   // 0, or LDSR_CELL_SINGULAR if Svv / Tuu cannot be inverted
+    int t_first_obs, t_last_obs;
+    double Syy;                             // sum_obs y_t^2
+    double Syv[LDSR_MAXPQ];                 // sum_obs y_t v_t            (:158)
+    double wv[LDSR_MAXPQ];                  // Svv^{-1} Syv
+    double Svv_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_obs v_t v_t')^{-1}   (:161), identity padded
+    double Tuu_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_{t<T-1} u_t u_t')^{-1} (:193), identity padded
+};
+
+template <int PP, int QQ>
+struct Theta {
+    double A, C, Q, R, mu1, V1;
+    double B[PP], D[QQ];
+};
+
+// E-step sufficient statistics consumed by the M-step (src/EM.cpp:151-152,159,180-183,190-191).
+template <int PP, int QQ>
+struct Sums {
+    double Syx;       // sum_obs y_t Xs_t
+    double Sxx;       // sum_obs Xs_t^2 + Vs_t
+    double Sxv[QQ];   // sum_obs Xs_t v_t
+    double Tx1x;      // sum_{t=0}^{T-2} Xs_{t+1} Xs_t + Vs_{t+1} J_t
+    double Txx;       // sum_{t=0}^{T-2} Xs_t^2 + Vs_t
+    double Tx1x1;     // sum_{t=1}^{T-1} Xs_t^2 + Vs_t
+    double Tx1u[PP];  // sum_{t=0}^{T-2} Xs_{t+1} u_t
+    double Tux[PP];   // sum_{t=0}^{T-2} u_t Xs_t
+    double X0, V0;    // Xs_0, Vs_0  -> mu1, V1 (:218-219)
+};
+
+template <int PP, int QQ>
+__device__ __forceinline__ void load_theta(Theta<PP, QQ> &th, const double *__restrict__ g, int p,
+                                           int q, bool has_u, bool has_v) {
+    th.A = g[0];
+#pragma unroll
+    for (int k = 0; k < PP; k++) th.B[k] = (has_u && k < p) ? g[1 + k] : 0.0;
+    th.C = g[1 + p];
+#pragma unroll
+    for (int k = 0; k < QQ; k++) th.D[k] = (has_v && k < q) ? g[2 + p + k] : 0.0;
+    th.Q = g[2 + p + q];
+    th.R = g[3 + p + q];
+    th.mu1 = g[4 + p + q];
+    th.V1 = g[5 + p + q];
+}
+
+template <int PP, int QQ>
+__device__ __forceinline__ void store_theta(const Theta<PP, QQ> &th, double *__restrict__ g, int p,
+                                            int q) {
+    g[0] = th.A;
+#pragma unroll
+    for (int k = 0; k < PP; k++)
+        if (k < p) g[1 + k] = th.B[k];
+    g[1 + p] = th.C;
+#pragma unroll
+    for (int k = 0; k < QQ; k++)
+        if (k < q) g[2 + p + k] = th.D[k];
+    g[2 + p + q] = th.Q;
+    g[3 + p + q] = th.R;
+    g[4 + p + q] = th.mu1;
+    g[5 + p + q] = th.V1;
+}
+
+// Closed-form M-step (src/EM.cpp:139-229).  The reference solves
+//   [C D] = [Syx Syv] inv([[Sxx Sxv],[Svx Svv]])   and   [A B] = [Tx1x Tx1u] inv([[Txx Txu],[Tux Tuu]])
+// with a dense inverse each call.  Svv and Tuu do not depend on theta, so their inverses are
+// per-series constants and the two systems reduce to a scalar Schur complement:
+//   zv = Svv^{-1} Sxv',  C = (Syx - Syv zv) / (Sxx - Sxv zv),  D = Svv^{-1} Syv' - C zv
+//   zu = Tuu^{-1} Tux,   A = (Tx1x - Tx1u zu) / (Txx - Txu zu), B = Tuu^{-1} Tx1u' - A zu
+// R uses the algebraic form of ((y - yhat) y')/n  (:177) and Q is the reference's (:210).
+template <int PP, int QQ>
+__device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, QQ> &S,
+                                             const SeriesConst *__restrict__ sc, int T) {
+    double zv[QQ];
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < QQ; l++) a = fma(sc->Svv_inv[k * LDSR_MAXPQ + l], S.Sxv[l], a);
+        zv[k] = a;
+    }
+    double numC = S.Syx, denC = S.Sxx;
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        numC = fma(-sc->Syv[k], zv[k], numC);
+        denC = fma(-S.Sxv[k], zv[k], denC);
+    }
+    const double C = numC / denC;
+    double racc = fma(-C, S.Syx, sc->Syy);
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        const double d = fma(-C, zv[k], sc->wv[k]);
+        th.D[k] = d;
+        racc = fma(-d, sc->Syv[k], racc);
+    }
+    th.C = C;
+    th.R = racc / (double)sc->n_obs;
+
+    double zu[PP], ru[PP];
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int l = 0; l < PP; l++) {
+            const double w = sc->Tuu_inv[k * LDSR_MAXPQ + l];
+            a = fma(w, S.Tux[l], a);
+            b = fma(w, S.Tx1u[l], b);
+        }
+        zu[k] = a;
+        ru[k] = b;
+    }
+    double numA = S.Tx1x, denA = S.Txx;
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        numA = fma(-S.Tx1u[k], zu[k], numA);
+        denA = fma(-S.Tux[k], zu[k], denA);
+    }
+    const double A = numA / denA;
+    double qacc = fma(-A, S.Tx1x, S.Tx1x1);
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        const double b = fma(-A, zu[k], ru[k]);
+        th.B[k] = b;
+        qacc = fma(-b, S.Tx1u[k], qacc);
+    }
+    th.A = A;
+    th.Q = qacc / (double)(T - 1);
+    th.mu1 = S.X0;
+    th.V1 = S.V0;
+}
+
+// Kernel argument block shared by the EM kernels.
+struct EmParams {
+    int T, p, q, has_u, has_v, niter, n_cells;
+    double tol;
+    const double *yp;        // [n_series][T]       NaN = missing
+    const double *up;        // [n_series or 1][T][PP]  zero padded, row T-1 zeroed
+    const double *vp;        // [n_series or 1][T][QQ]
+    long u_stride, v_stride; // doubles per series (0 when shared)
+    const SeriesConst *sc;   // [n_series]
+    const int *blk_series, *blk_cell0, *blk_ncell;  // block table
+    const double *theta0;    // [n_cells][6+p+q]
+    double *theta, *lik, *liks;
+    int *n_iter, *status;
+    double *scratch;         // serial kernel: [T][2][scratch_stride]
+    long scratch_stride;
+};
+
+#define LDSR_LOG_2PI 1.8378770664093454835606594728112

@@ -1,0 +1,35 @@
+// ldsr_kernels.h -- host-visible launch interface between the C ABI (ldsr_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ldsr_device.h"
+
+struct PrepParams {
+    int T, p, q, PP, QQ, shared_uv;
+    const double *y, *u, *v;  // raw inputs as handed over the ABI (u / v may be null)
+    double *yp, *up, *vp;     // prepared copies in the workspace
+    SeriesConst *sc;
+};
+
+struct SmoothParams {
+    int T, p, q, has_u, has_v, n_cells, stdlik, mode;
+    const double *yp, *up, *vp;
+    long u_stride, v_stride;
+    const SeriesConst *sc;
+    const int *series_of_cell;
+    const double *theta;  // [n_cells][P] input (smooth / propagate)
+    double *X, *Y, *V, *J, *lik;
+    double *theta_out;    // mstep
+    int *status;
+};
+
+static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+
+hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream);
+hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int waves_per_block,
+                          hipStream_t stream);
+bool em_scan_supported(int T, int PP, int QQ);
+int em_scan_waves_per_block(int T, int PP, int QQ);
+hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);
+hipError_t launch_mstep(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);

@@ -1,0 +1,330 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C ABI
+of include/ldsr_hip.h; the CPU oracle is only the checker.
+
+Bar (BASELINE.json north_star): identical EM iteration counts, then
+|d| <= 1e-6*|ref| + 1e-9 on every theta entry and on the log-likelihood."""
+import numpy as np
+import pytest
+
+from conftest import parity_close
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-6, 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import ldsr_amd
+    from ldsr_amd import _lib
+    assert _lib.lib().ldsr_device_count() >= 1, "no GPU visible"
+    return ldsr_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+import os
+
+ALGOS = [int(a) for a in os.environ.get("LDSR_TEST_ALGOS", "1,2").split(",")]   # 1 = LDSR_ALGO_SERIAL, 2 = LDSR_ALGO_SCAN
+
+
+def _oracle_batch(O, y, u, v, th0, niter, tol, soc=None, threads=8):
+    Y = np.atleast_2d(y)
+    U = None if u is None else (u.T[None] if u.ndim == 2 else np.transpose(u, (0, 2, 1)))
+    V = None if v is None else (v.T[None] if v.ndim == 2 else np.transpose(v, (0, 2, 1)))
+    S = Y.shape[0]
+    if U is not None and U.shape[0] != S:
+        U = np.repeat(U, S, axis=0)
+    if V is not None and V.shape[0] != S:
+        V = np.repeat(V, S, axis=0)
+    if soc is None:
+        soc = np.zeros(th0.shape[0], np.int32)
+    return O.em_batch(Y, None if U is None else np.ascontiguousarray(U),
+                      None if V is None else np.ascontiguousarray(V), soc, th0, niter, tol,
+                      n_threads=threads)
+
+
+def _assert_batch_parity(r, ref, what=""):
+    ref_th, ref_lik, ref_it, ref_st = ref
+    assert np.array_equal(r["n_iter"], ref_it), "%s: iteration counts differ at cells %s" % (
+        what, np.nonzero(r["n_iter"] != ref_it)[0][:10])
+    assert parity_close(r["lik"], ref_lik, RTOL, ATOL), what
+    assert parity_close(r["theta"], ref_th, RTOL, ATOL), what
+
+
+# ---- the reference's own known-answer test, through the GPU ---------------------------------
+def test_known_answer_first_two_iterations(eng, p1case):
+    """tests/testthat/test-LDS-EM.R:21-35 with the same call sequence and tolerance."""
+    c = p1case
+    smooth1 = eng.Kalman_smoother(c["y"], c["u"], c["v"], c["theta0"])
+    theta1 = eng.Mstep(c["y"], c["u"], c["v"], smooth1)
+    smooth2 = eng.Kalman_smoother(c["y"], c["u"], c["v"], theta1)
+    theta2 = eng.Mstep(c["y"], c["u"], c["v"], smooth2)
+    tol = 1e-6
+    assert smooth1["lik"] == pytest.approx(-11.678657, abs=tol)
+    assert smooth1["X"][0, [0, 84]] == pytest.approx([1.293356, -0.987671], abs=tol)
+    assert theta1["A"][0, 0] == pytest.approx(0.606066, abs=tol)
+    assert theta1["C"][0, 0] == pytest.approx(-0.005995, abs=tol)
+    assert theta1["Q"][0, 0] == pytest.approx(3.640236, abs=tol)
+    assert smooth2["lik"] == pytest.approx(-0.114224, abs=tol)
+    assert theta2["A"][0, 0] == pytest.approx(0.603945, abs=tol)
+    assert theta2["C"][0, 0] == pytest.approx(-0.012004, abs=tol)
+    assert theta2["Q"][0, 0] == pytest.approx(3.644322, abs=tol)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_known_answer_convergence(eng, p1case, algo):
+    """tests/testthat/test-LDS-EM.R:37-41: 68 iterations, lik = -0.039093."""
+    c = p1case
+    fit = eng.LDS_EM(c["y"], c["u"], c["v"], c["theta0"], 100, 1e-5, algo=algo)
+    assert len(fit["liks"]) == 68
+    assert fit["lik"] == pytest.approx(-0.039093, abs=1e-6)
+    assert fit["fit"]["lik"] == pytest.approx(fit["lik"], abs=1e-12)
+
+
+def test_smoother_full_fit_matches_oracle(eng, O, p1case):
+    c = p1case
+    g = eng.Kalman_smoother(c["y"], c["u"], c["v"], c["theta0"])
+    r = O.kalman_smoother(c["y"], c["u"], c["v"], c["theta0"])
+    for k in "XYVJ":
+        assert parity_close(g[k][0], r[k], RTOL, ATOL), k
+    assert parity_close(g["lik"], r["lik"], RTOL, ATOL)
+    g = eng.Kalman_smoother(c["y"], c["u"], c["v"], c["theta0"], stdlik=False)
+    r = O.kalman_smoother(c["y"], c["u"], c["v"], c["theta0"], stdlik=False)
+    assert parity_close(g["lik"], r["lik"], RTOL, ATOL)
+
+
+def test_propagate_matches_oracle(eng, O, p1case):
+    c = p1case
+    y = c["y"].copy()
+    y[[3, 4, 50]] = np.nan
+    g = eng.propagate(c["theta0"], c["u"], c["v"], y)
+    r = O.propagate(c["theta0"], c["u"], c["v"], y)
+    for k in "XYV":
+        assert parity_close(g[k][0], r[k], RTOL, ATOL), k
+    assert parity_close(g["lik"], r["lik"], RTOL, ATOL)
+
+
+# ---- branches the reference only smoke-tests --------------------------------------------------
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("case", ["u_absent", "v_absent", "nan_mask", "p2_q7", "both_p3_q5"])
+def test_branches_on_p1_data(eng, O, p1case, case, algo):
+    c = p1case
+    y, u, v = c["y"].copy(), c["u"], c["v"]
+    if case == "u_absent":
+        u = None
+    if case == "v_absent":
+        v = None
+    if case == "nan_mask":
+        y[[0, 10, 11, 84]] = np.nan
+    if case == "p2_q7":
+        u = u[:2]
+    if case == "both_p3_q5":
+        u, v = u[:3], v[2:7]
+    p = 1 if u is None else u.shape[0]
+    q = 1 if v is None else v.shape[0]
+    from ldsr_amd import synth
+    th0 = synth.make_init_packed(p, q, 40, seed=11)
+    th0[0] = np.concatenate([[0.5], np.full(p, 0.5), [0.5], np.full(q, 0.5), [1, 1, 1, 1.0]])
+    r = eng.em_batch(y, u, v, th0, niter=100, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 100, 1e-5)
+    _assert_batch_parity(r, ref, case)
+    if u is None:
+        assert np.all(r["theta"][:, 1] == 0.0)          # B.zeros(1,p), src/EM.cpp:186
+    if v is None:
+        assert np.all(r["theta"][:, 2 + p] == 0.0)      # D.zeros(1,q), src/EM.cpp:154
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_np_bundled_data_restarts(eng, O, npcase, refdata, algo):
+    """Config 1: bundled Nakhon Phanom data, the reference test's slice t(NPpc[601:813])
+    (start.year = 1800, T = 213, 46 observations, p = q = 3), 50 restarts, niter=1000."""
+    c = npcase(1800)
+    from ldsr_amd import synth
+    th0 = synth.make_init_packed(3, 3, 50, seed=5)
+    r = eng.em_batch(c["y"], c["u"], c["v"], th0, niter=1000, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, c["y"], c["u"], c["v"], th0, 1000, 1e-5)
+    _assert_batch_parity(r, ref, "NP T=213")
+    k = eng.select_restart(r["lik"], r["theta"], 3, 3)
+    assert k == O.select(ref[1], ref[0][:, 4])
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_np_full_length_paleo_mask(eng, O, npcase, algo):
+    """NP data from 1200 (T = 813, 767 leading NA): mu1 / V1 stay at their initial values."""
+    c = npcase(1200)
+    from ldsr_amd import synth
+    th0 = synth.make_init_packed(3, 3, 16, seed=6)
+    r = eng.em_batch(c["y"], c["u"], c["v"], th0, niter=300, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, c["y"], c["u"], c["v"], th0, 300, 1e-5)
+    _assert_batch_parity(r, ref, "NP T=813")
+
+
+# ---- synthetic configs of BASELINE.json at oracle-sized cell counts ---------------------------
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("T,p,q,mask,n", [
+    (1000, 1, 2, "dense", 192),     # config 2 shape
+    (1000, 1, 2, "paleo", 64),
+    (1000, 4, 8, "dense", 64),      # config 3 shape (5x5 and 9x9 systems)
+    (2000, 1, 4, "dense", 32),      # config 4 shape
+    (813, 1, 3, "paleo", 32),       # config 5 shape
+    (64, 1, 1, "dense", 8),
+    (65, 2, 1, "dense", 8),
+    (256, 3, 5, "dense", 8),
+    (257, 8, 8, "paleo", 8),
+    (1024, 2, 2, "dense", 8),
+    (1025, 1, 1, "dense", 8),
+    (2048, 2, 4, "paleo", 8),
+    (2049, 1, 2, "dense", 8),       # beyond the scan kernel: AUTO / SCAN must refuse or fall back
+])
+def test_synthetic_converged_runs(eng, O, algo, T, p, q, mask, n):
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(T, p, q, series_id=T + p + q, mask=mask)
+    th0 = synth.make_init_packed(p, q, n, seed=T)
+    if algo == 2 and T > 2048:
+        with pytest.raises(Exception):
+            eng.em_batch(y, u, v, th0, niter=1000, tol=1e-5, algo=algo)
+        algo = 0                     # LDSR_ALGO_AUTO falls back to the serial kernel
+    r = eng.em_batch(y, u, v, th0, niter=1000, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 1000, 1e-5)
+    assert np.all(np.isfinite(ref[1]))
+    _assert_batch_parity(r, ref, "T=%d p=%d q=%d %s" % (T, p, q, mask))
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("T,p,q", [(2, 1, 1), (3, 1, 1), (3, 1, 2), (5, 2, 2), (7, 2, 2), (9, 8, 8)])
+def test_tiny_series_fixed_iterations(eng, O, algo, T, p, q):
+    """Smallest lengths the reference can run (T >= 2).  These problems have more parameters
+    than data, EM drives R -> 0, so only a few iterations are compared."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(max(T, 12), p, q, series_id=50 + T)
+    y, u, v = y[:T], u[:, :T], v[:, :T]
+    th0 = synth.make_init_packed(p, q, 6, seed=T)
+    if T <= max(p, q):               # Svv / Tuu singular: flagged, as arma::inv would throw
+        r = eng.em_batch(y, u, v, th0, niter=3, tol=0.0, algo=algo)
+        assert np.all(r["status"] == 2)
+        return
+    r = eng.em_batch(y, u, v, th0, niter=3, tol=0.0, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 3, 0.0)
+    _assert_batch_parity(r, ref, "tiny T=%d" % T)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_fixed_niter_and_liks_trace(eng, O, algo):
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(500, 1, 2, series_id=3)
+    th0 = synth.make_init_packed(1, 2, 16, seed=2)
+    r = eng.em_batch(y, u, v, th0, niter=25, tol=0.0, algo=algo, return_liks=True)
+    assert np.all(r["n_iter"] == 25)
+    for c in range(4):
+        ref = O.lds_em(y, u, v, th0[c], 25, 0.0)
+        assert parity_close(r["liks"][c], ref["liks"], RTOL, ATOL)
+    # EM never decreases the (incomplete-data) likelihood
+    assert np.all(np.diff(r["liks"], axis=1) > -1e-9)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_cv_fold_grid_shared_inputs(eng, O, algo):
+    """cvLDS shape (R/LDS_reconstruction.R:270-285): same u, v; one NA mask of y per fold;
+    fresh restarts per fold; ragged cell counts per fold, one fold with no restarts."""
+    from ldsr_amd import synth
+    T, p, q = 400, 1, 4
+    y, u, v = synth.make_series(T, p, q, series_id=9, mask="paleo", n_tail=100)
+    folds = []
+    for k in range(4):
+        yk = y.copy()
+        yk[300 + 25 * k:300 + 25 * k + 11] = np.nan     # contiguous block of the instrumental period
+        folds.append(yk)
+    Y = np.stack(folds)
+    counts = [5, 0, 9, 3]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    th0 = synth.make_init_packed(p, q, off[-1], seed=8)
+    r = eng.em_batch(Y, u, v, th0, cell_offsets=off, niter=200, tol=1e-5, algo=algo)
+    soc = np.repeat(np.arange(4), counts).astype(np.int32)
+    ref = _oracle_batch(O, Y, u, v, th0, 200, 1e-5, soc=soc)
+    _assert_batch_parity(r, ref, "cv grid")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_multi_series_own_inputs(eng, O, algo):
+    """48-station shape (config 5): independent series with their own u, v and NA pattern."""
+    from ldsr_amd import synth
+    T, p, q, S, n = 300, 1, 3, 5, 7
+    ys, us, vs = zip(*[synth.make_series(T, p, q, series_id=100 + s, mask="paleo",
+                                         n_tail=30 + 12 * s) for s in range(S)])
+    Y, U, V = np.stack(ys), np.stack(us), np.stack(vs)
+    off = (np.arange(S + 1) * n).astype(np.int32)
+    th0 = synth.make_init_packed(p, q, S * n, seed=4)
+    r = eng.em_batch(Y, U, V, th0, cell_offsets=off, niter=150, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, Y, U, V, th0, 150, 1e-5, soc=np.repeat(np.arange(S), n).astype(np.int32))
+    _assert_batch_parity(r, ref, "multi series")
+
+
+def test_restart_selection_and_winner_fit(eng, O, p1case):
+    c = p1case
+    init = eng.make_init(7, 7, 24, seed=1)
+    win = eng.LDS_EM_restart(c["y"], c["u"], c["v"], init, niter=100, tol=1e-5)
+    th0 = np.stack([eng.pack_theta(t, 7, 7) for t in init])
+    ref = _oracle_batch(O, c["y"], c["u"], c["v"], th0, 100, 1e-5)
+    k = O.select(ref[1], ref[0][:, 8])
+    assert win["all"]["selected"] == k
+    assert win["theta"]["C"][0, 0] > 0 or not np.any(ref[0][:, 8] > 0)
+    full = O.lds_em(c["y"], c["u"], c["v"], th0[k], 100, 1e-5)
+    for key in "XYVJ":
+        assert parity_close(win["fit"][key][0], full["fit"][key], RTOL, ATOL), key
+    assert parity_close(win["liks"], full["liks"], RTOL, ATOL)
+    assert win["init"] is init[k]
+
+
+def test_singular_inputs_are_flagged_not_trapped(eng):
+    """Duplicate rows of v make Svv singular: arma::inv throws in the reference; the device
+    path marks every cell LDSR_CELL_SINGULAR and the host API raises."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(100, 1, 2, series_id=1)
+    v[1] = v[0]
+    th0 = synth.make_init_packed(1, 2, 4, seed=1)
+    r = eng.em_batch(y, u, v, th0, niter=10)
+    assert np.all(r["status"] == 2) and np.all(np.isnan(r["lik"]))
+    with pytest.raises(Exception):
+        eng.LDS_EM(y, u, v, th0[0], 10, 1e-5)
+
+
+def test_argument_errors(eng):
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(50, 1, 2)
+    th0 = synth.make_init_packed(1, 2, 2)
+    with pytest.raises(Exception):
+        eng.em_batch(y, u, v, th0, niter=1)              # reference reads lik[1]
+    with pytest.raises(Exception):
+        eng.em_batch(y, np.zeros((9, 50)), v, synth.make_init_packed(9, 2, 2))   # p > 8
+
+
+# ---- full BASELINE sizes: size-independent properties + sampled oracle parity -----------------
+@pytest.mark.parametrize("algo", ALGOS)
+def test_config2_full_size(eng, O, algo):
+    """Config 2 as benchmarked: T=1000, p=1, q=2, 4096 restarts, niter=100, tol=0."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(1000, 1, 2, series_id=0)
+    th0 = synth.make_init_packed(1, 2, 4096, seed=1)
+    r = eng.em_batch(y, u, v, th0, niter=100, tol=0.0, algo=algo, return_liks=True)
+    assert np.all(r["n_iter"] == 100)
+    assert np.all(r["status"] == 0)
+    assert np.all(np.diff(r["liks"], axis=1) > -1e-9)            # EM monotonicity, every cell
+    # sharding independence: a sub-batch gives bit-identical results
+    sub = eng.em_batch(y, u, v, th0[1000:1100], niter=100, tol=0.0, algo=algo)
+    assert np.array_equal(sub["theta"], r["theta"][1000:1100])
+    # sign symmetry of the model (x,B,C,mu1 -> -x,-B,-C,-mu1 leaves the likelihood unchanged)
+    flip = th0[:64].copy()
+    flip[:, 1] *= -1
+    flip[:, 2] *= -1
+    f = eng.em_batch(y, u, v, flip, niter=100, tol=0.0, algo=algo)
+    assert parity_close(f["lik"], r["lik"][:64], 1e-9, 1e-12)
+    assert parity_close(f["theta"][:, 2], -r["theta"][:64, 2], 1e-9, 1e-12)
+    # oracle on every 16th cell
+    idx = np.arange(0, 4096, 16)
+    ref = _oracle_batch(O, y, u, v, th0[idx], 100, 0.0, threads=16)
+    _assert_batch_parity({k: r[k][idx] for k in ("theta", "lik", "n_iter")}, ref, "cfg2 full")
