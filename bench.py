@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- restart x EM-iteration throughput of the EM/Kalman hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: a single ldsr_em_batch_device call
+(series preparation + the EM kernel) on BASELINE.json's config 2 -- synthetic T=1000, p=1,
+q=2, 4096 restarts per GPU, niter=100, tol=0 (the stop rule of src/EM.cpp:272 can never fire,
+so every cell runs exactly 100 E-steps) = 409 600 restart x EM-iteration units per GPU.
+Inputs (y, u, v, theta0) are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run): restarts shard embarrassingly -- every rank runs
+its own 4096 restarts of the same series (restart index = rank*4096 + i in the counter-based
+generator), no data-path collective; "scaling": "weak".
+
+Prints ONE JSON line on rank 0; see the task contract for the fields.  Extra objects:
+  roofline      algorithmic bytes (16*T*(3+p+q) per unit) / EM-kernel time
+                measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of src/EM.cpp, not RcppArmadillo) on the host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (T, p, q, cells per GPU, niter)
+    "cfg2": (1000, 1, 2, 4096, 100),
+    "cfg3": (1000, 4, 8, 8192, 100),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def bytes_per_unit(T, p, q):
+    return 16 * T * (3 + p + q)
+
+
+def load_pmc_traffic(workload):
+    """HBM bytes per EM-kernel launch from the committed rocprofv3 --pmc summary, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(T, p, q, niter, y, u, v, seed):
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    from ldsr_amd import synth
+    cells = 256 * cores
+    th0 = synth.make_init_packed(p, q, cells, seed=seed)
+    Y = y[None]
+    U = np.ascontiguousarray(u.T[None])
+    V = np.ascontiguousarray(v.T[None])
+    soc = np.zeros(cells, np.int32)
+    O.em_batch(Y, U, V, soc[:cores], th0[:cores], 3, 0.0, n_threads=cores)      # warm
+    t0 = time.perf_counter()
+    O.em_batch(Y, U, V, soc, th0, niter, 0.0, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": cells * niter / dt, "unit": "restart*EM-iter/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d restarts x %d EM iterations of the same series, %d host threads, %.1f s "
+                      "(CPU oracle = scalar fp64 port of src/EM.cpp, not RcppArmadillo)"
+                      % (cells, niter, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan")
+    ap.add_argument("--mask", default="dense", choices=["dense", "paleo"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ldsr_amd import _lib, synth
+    L = _lib.lib()
+
+    T, p, q, cells, niter = WORKLOADS[args.workload]
+    P = 6 + p + q
+    y, u, v = synth.make_series(T, p, q, series_id=0, mask=args.mask)
+    th0 = synth.make_init_packed(p, q, cells, seed=1, first=rank * cells)
+
+    d_y = torch.from_numpy(y).to(dev)
+    d_u = torch.from_numpy(np.ascontiguousarray(u.T)).to(dev)       # [T][p]
+    d_v = torch.from_numpy(np.ascontiguousarray(v.T)).to(dev)       # [T][q]
+    d_th0 = torch.from_numpy(th0).to(dev)
+    d_th = torch.empty_like(d_th0)
+    d_lik = torch.empty(cells, dtype=torch.float64, device=dev)
+    d_nit = torch.empty(cells, dtype=torch.int32, device=dev)
+    d_st = torch.empty(cells, dtype=torch.int32, device=dev)
+    wsb = L.ldsr_em_workspace_bytes(1, T, p, q, cells, args.algo)
+    assert wsb > 0
+    d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (d_ws.data_ptr() + 255) & ~255
+    off = (C.c_int * 2)(0, cells)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        _lib.check(L.ldsr_em_batch_device(
+            local_rank, C.c_void_p(stream.cuda_stream), 1, T, p, q, d_y.data_ptr(),
+            d_u.data_ptr(), d_v.data_ptr(), 0, off, d_th0.data_ptr(), niter, 0.0, args.algo,
+            d_th.data_ptr(), d_lik.data_ptr(), d_nit.data_ptr(), d_st.data_ptr(), None,
+            C.c_void_p(ws_ptr), wsb))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.ldsr_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms = C.c_double()
+    n_l = C.c_int()
+    _lib.check(L.ldsr_profile_collect(C.byref(tot_ms), C.byref(n_l)))
+    L.ldsr_profile_enable(0)
+
+    # the run must have done the work it claims
+    nit = d_nit.cpu().numpy()
+    st = d_st.cpu().numpy()
+    assert np.all(nit == niter), "cells stopped early"
+    assert np.all(st == 0), "non-finite likelihoods in the bench batch"
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        units_per_step = cells * niter * world
+        value = units_per_step * args.steps / dt
+        kern_ms = tot_ms.value / max(n_l.value, 1)
+        bpu = bytes_per_unit(T, p, q)
+        alg_bytes = bpu * cells * niter                       # per launch (one GPU)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
+            "value": value, "unit": "restart*EM-iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: synthetic T=%d p=%d q=%d, %d restarts/GPU, niter=%d, "
+                                   "tol=0, %s mask" % (args.workload, T, p, q, cells, niter,
+                                                       args.mask),
+                       "restarts_per_gpu": cells, "niter": niter, "algo": args.algo,
+                       "units_per_step": units_per_step, "sharding": "restarts/%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_pmc_traffic(args.workload),
+                         "kernel": "em_scan_kernel" if args.algo != 1 else "em_serial_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_unit": bpu,
+                         "units_per_launch": cells * niter,
+                         "note": "algorithmic (logical) traffic; the series is served from LDS "
+                                 "and the filtered states never leave registers, so measured "
+                                 "HBM traffic is far below it"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, p, q, niter, y, u, v, seed=1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,12 @@ int ldsr_propagate_batch(int device, int n_series, int T, int p, int q, const do
                          const int *cell_offsets, const double *theta, int stdlik, double *X,
                          double *Y, double *V, double *lik);
 
+/* Optional kernel timer.  While enabled, every ldsr_em_batch_device call brackets its EM
+ * kernel with HIP events on the launch stream; collect() waits for them and returns the summed
+ * kernel time and the number of launches since the last collect / enable. */
+void ldsr_profile_enable(int on);
+int ldsr_profile_collect(double *total_ms, int *n_launches);
+
 /* Restart selection on the host: index of the winning cell among n, or -1. */
 int ldsr_select_restart(int n, const double *lik, const double *theta, int p, int q);
 

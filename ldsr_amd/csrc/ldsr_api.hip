@@ -34,7 +34,56 @@ extern "C" int ldsr_device_count(void) {
     return n;
 }
 
-extern "C" void ldsr_shutdown(void) {}
+// ---- optional kernel timer: HIP events around the EM kernel, on its launch stream ------------
+static struct {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+} g_prof;
+
+extern "C" void ldsr_profile_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+}
+
+extern "C" int ldsr_profile_collect(double *total_ms, int *n_launches) {
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof.used; i++) {
+        HIPCHK(hipEventSynchronize(g_prof.ev[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (n_launches) *n_launches = (int)g_prof.used;
+    g_prof.used = 0;
+    return LDSR_OK;
+}
+
+static hipError_t prof_mark(hipStream_t stream, bool end) {
+    if (!g_prof.on) return hipSuccess;
+    if (!end) {
+        if (g_prof.used == g_prof.ev.size()) {
+            hipEvent_t a, b;
+            hipError_t e = hipEventCreate(&a);
+            if (e != hipSuccess) return e;
+            e = hipEventCreate(&b);
+            if (e != hipSuccess) return e;
+            g_prof.ev.emplace_back(a, b);
+        }
+        return hipEventRecord(g_prof.ev[g_prof.used].first, stream);
+    }
+    return hipEventRecord(g_prof.ev[g_prof.used++].second, stream);
+}
+
+extern "C" void ldsr_shutdown(void) {
+    for (auto &p : g_prof.ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    g_prof.ev.clear();
+    g_prof.used = 0;
+}
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -179,10 +228,12 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     prm.n_iter = d_n_iter; prm.status = d_status;
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
+    HIPCHK(prof_mark(stream, false));
     if (algo == LDSR_ALGO_SCAN)
         HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, cpb, stream));
     else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
+    HIPCHK(prof_mark(stream, true));
     return LDSR_OK;
 }
 
