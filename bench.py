@@ -51,15 +51,27 @@ def load_pmc_traffic(workload):
         return None
 
 
+def host_cores():
+    """Usable host cores: affinity mask, capped by the cgroup CPU quota (the GPU box exposes
+    256 CPUs but grants a 16-core share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(T, p, q, niter, y, u, v, seed):
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     from ldsr_amd import synth
-    cells = 256 * cores
+    cells = 512 * cores
     th0 = synth.make_init_packed(p, q, cells, seed=seed)
     Y = y[None]
     U = np.ascontiguousarray(u.T[None])

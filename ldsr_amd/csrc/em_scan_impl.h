@@ -109,12 +109,25 @@ __device__ __forceinline__ PMat pshfl_up(const PMat &m, int d) {
     return r;
 }
 
+// Lane <-> time mapping.  A cell uses nl = ceil(T/L) lanes; the first rp lanes own L
+// consecutive steps and lanes rp..nl-1 own L-1 (T = nl*(L-1) + rp), so steps 0..L-2 of every
+// active lane are real and only step L-1 is predicated: the unrolled loops are straight-line
+// code.  Lane l starts at t0 = l*(L-1) + min(l, rp).  Requires L*(L-1) <= T <= 64*L (see
+// scan_L_for in kernels_scan.hip).
+
+
+// DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
+template <int PP, int QQ, int L, bool DENSE>
+__device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
+                                             const double *us, const double *vs, int s, int cell,
+                                             int lane, int nl, int rp);
+
 template <int PP, int QQ, int L>
 __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
     // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
-    double *ys = smem;                  // [L][64]       y, 0 where missing / beyond T
-    double *us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t >= T-1
+    double *ys = smem;                  // [L][64]       y, 0 where missing / unused
+    double *us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t = T-1
     double *vs = us + 64 * L * PP;      // [L][QQ][64]   v_t
 
     const int b = blockIdx.x;
@@ -123,43 +136,60 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
     const int T = prm.T;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int nl = (T + L - 1) / L;          // active lanes
+    const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
     {
         const double *gy = prm.yp + (long)s * T;
         const double *gu = prm.up + (long)s * prm.u_stride;
         const double *gv = prm.vp + (long)s * prm.v_stride;
         for (int i = threadIdx.x; i < 64 * L; i += blockDim.x) {
-            const int j = i >> 6, l = i & 63, t = l * L + j;
-            double yv = (t < T) ? gy[t] : 0.0;
+            const int j = i >> 6, l = i & 63, t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            double yv = ok ? gy[t] : 0.0;
             ys[i] = isfinite(yv) ? yv : 0.0;
         }
         for (int i = threadIdx.x; i < 64 * L * PP; i += blockDim.x) {
-            const int l = i & 63, jk = i >> 6, j = jk / PP, k = jk - j * PP, t = l * L + j;
-            us[i] = (t < T) ? gu[(long)t * PP + k] : 0.0;
+            const int l = i & 63, jk = i >> 6, j = jk / PP, k = jk - j * PP;
+            const int t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            us[i] = ok ? gu[(long)t * PP + k] : 0.0;
         }
         for (int i = threadIdx.x; i < 64 * L * QQ; i += blockDim.x) {
-            const int l = i & 63, jk = i >> 6, j = jk / QQ, k = jk - j * QQ, t = l * L + j;
-            vs[i] = (t < T) ? gv[(long)t * QQ + k] : 0.0;
+            const int l = i & 63, jk = i >> 6, j = jk / QQ, k = jk - j * QQ;
+            const int t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            vs[i] = ok ? gv[(long)t * QQ + k] : 0.0;
         }
     }
     __syncthreads();
     if (wave >= nc) return;   // whole wave leaves; no barrier follows
-
     const int cell = c0 + wave;
+    if (prm.sc[s].n_obs == T)
+        em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, cell, lane, nl, rp);
+    else
+        em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, cell, lane, nl, rp);
+}
+
+template <int PP, int QQ, int L, bool DENSE>
+__device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
+                                             const double *us, const double *vs, int s, int cell,
+                                             int lane, int nl, int rp) {
+    const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
     const int n_obs = sc->n_obs;
-    const int t0 = lane * L;
-    const int nvalid = min(max(T - t0, 0), L);
-    const int lastLane = (T - 1) / L, jLast = (T - 1) - lastLane * L;  // owner of step T-1
+    const bool act = lane < nl;      // this lane owns time steps
+    const bool tail = lane < rp;     // ... and its chunk has the L-th step
+    const int lastLane = nl - 1;     // owner of step T-1
 
     // observation mask of this lane's chunk
     unsigned obsmask = 0;
-    {
+    if (!DENSE && act) {
         const double *gy = prm.yp + (long)s * T;
+        const int t0 = lane * (L - 1) + min(lane, rp);
 #pragma unroll
         for (int j = 0; j < L; j++) {
-            const int t = t0 + j;
-            const double yv = (t < T) ? gy[t] : NAN;
+            const double yv = (j < L - 1 || tail) ? gy[t0 + j] : NAN;
             if (isfinite(yv)) obsmask |= (1u << j);
         }
     }
@@ -190,29 +220,31 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
         // ------------------------------------------------ F1: compose this lane's step matrices
         PMat M;
         M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
+        auto f1 = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            double e = ys[j * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-            if (j < nvalid) {
-                const bool o = (obsmask >> j) & 1u;
-                double e = ys[j * 64 + lane];
+            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+            double bu = 0.0;
 #pragma unroll
-                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
-                double bu = 0.0;
+            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            PMat S;
+            S.m00 = o ? alpha : A2R;
+            S.m01 = QR;
+            S.m10 = o ? C2 : 0.0;
+            S.m11 = R;
+            S.m20 = o ? fma(bu, C2, AC * e) : 0.0;
+            S.m21 = bu * R;
+            S.m22 = AR;
+            if (j == 0) M = S; else M = pmul(S, M);
+            if ((j & 7) == 7 && j < L - 2) prenorm(M);
+        };
+        if (act) {
 #pragma unroll
-                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
-                PMat S;
-                S.m00 = o ? alpha : A2R;
-                S.m01 = QR;
-                S.m10 = o ? C2 : 0.0;
-                S.m11 = R;
-                S.m20 = o ? fma(bu, C2, AC * e) : 0.0;
-                S.m21 = bu * R;
-                S.m22 = AR;
-                if (j == 0) M = S; else M = pmul(S, M);
-                if ((j & 7) == 7 && j != L - 1) prenorm(M);
-            }
+            for (int j = 0; j < L - 1; j++) f1(j);
+            if (tail) f1(L - 1);
+            prenorm(M);
         }
-        prenorm(M);
 
         // ------------------------------------------------ forward scan (inclusive, by lane)
 #pragma unroll
@@ -236,56 +268,65 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
         }
 
         // ------------------------------------------------ F2: serial re-run from the exact entry
-        double likq = 0.0, sprod = 1.0, smin = 1.0;
-        double r0 = fast_rcp(fma(C2, Vp, R));
+        double likq = 0.0, sprod = 1.0, Xu = 0.0, Vu = 0.0;
+        int sneg = 0;   // OR of the sign words of every observed Sigma_t
+        double sg = fma(C2, Vp, R);     // Sigma_t of the current step (src/EM.cpp:119)
+        double r0 = fast_rcp(sg);
+        auto f2 = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            double e = ys[j * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-            if (j < nvalid) {
-                const bool o = (obsmask >> j) & 1u;
-                double e = ys[j * 64 + lane];
+            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+            double bu = 0.0;
 #pragma unroll
-                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
-                double bu = 0.0;
+            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            const double r = o ? r0 : 0.0;             // 1/Sigma_t; 0 = "no update" (:82-84)
+            const double sl = o ? sg : 1.0;
+            sprod *= sl;
+            sneg |= __double2hiint(sl);
+            const double w = Vp * r;
+            const double K = C * w;                    // :86
+            Vu = fma(-(C2 * w), Vp, Vp);               // (1 - K C) Vp  :88
+            const double dl = fma(-C, Xp, e);          // y - Yp
+            Xu = fma(K, dl, Xp);                       // :87
+            likq = fma(dl * r, dl, likq);              // delta/Sigma*delta  :122
+            const double Vp1 = fma(A2, Vu, Q);         // :76
+            const double Xp1 = fma(A, Xu, bu);         // :74
+            sg = fma(C2, Vp1, R);
+            const double z = fast_rcp(sg * Vp1);       // one reciprocal for 1/Vp1 and 1/Sigma_{t+1}
+            const double rp1 = sg * z;
+            r0 = Vp1 * z;
+            const double AVu = A * Vu;
+            const double J = AVu * rp1;                // :100
+            Jv[j] = J;
+            gv_[j] = fma(-J, Xp1, Xu);
+            hv[j] = fma(-J, AVu, Vu);
+            Xp = Xp1;
+            Vp = Vp1;
+        };
+        if (act) {
 #pragma unroll
-                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
-                const double sg = fma(C2, Vp, R);          // Sigma_t  (src/EM.cpp:119)
-                const double r = o ? r0 : 0.0;             // 1/Sigma_t, 0 = "no update" (:82-84)
-                const double sl = o ? sg : 1.0;
-                sprod *= sl;
-                smin = fmin(smin, sl);
-                const double w = Vp * r;
-                const double K = C * w;                    // :86
-                const double Vu = fma(-(C2 * w), Vp, Vp);  // (1 - K C) Vp  :88
-                const double dl = fma(-C, Xp, e);          // y - Yp
-                const double Xu = fma(K, dl, Xp);          // :87
-                likq = fma(dl * r, dl, likq);              // delta/Sigma*delta  :122
-                const double Vp1 = fma(A2, Vu, Q);         // :76
-                const double Xp1 = fma(A, Xu, bu);         // :74
-                const double sg1 = fma(C2, Vp1, R);
-                const double z = fast_rcp(sg1 * Vp1);      // one reciprocal for 1/Vp1 and 1/sg1
-                const double rp = sg1 * z;
-                r0 = Vp1 * z;
-                const double AVu = A * Vu;
-                const double J = AVu * rp;                 // :100 (and :98 for t = T-1)
-                Jv[j] = J;
-                gv_[j] = fma(-J, Xp1, Xu);
-                hv[j] = fma(-J, AVu, Vu);
-                Xp = Xp1;
-                Vp = Vp1;
-            }
+            for (int j = 0; j < L - 1; j++) f2(j);
+            if (tail) f2(L - 1);
         }
-        // terminal state (Xp_T, Vp_T): Xs_{T-1} = Xu_{T-1} + J_{T-1}(Xp_T - Xp_T)
-        const double XT = readlane_d(Xp, 63), VT = readlane_d(Vp, 63);
+        // Step T-1 starts the backward recursion: Xs_{T-1} = Xu_{T-1}, Vs_{T-1} = Vu_{T-1}
+        // (:94-95).  Expressed as J = 0, g = Xu, h = Vu with a zero terminal value, which also
+        // makes the (T-1, T) term of every pair sum vanish.
+        if (lane == lastLane) {
+            if (tail) { Jv[L - 1] = 0.0; gv_[L - 1] = Xu; hv[L - 1] = Vu; }
+            else      { Jv[L - 2] = 0.0; gv_[L - 2] = Xu; hv[L - 2] = Vu; }
+        }
+        const double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);   // Xs^2 + Vs at T-1
 
         // likelihood (:113-124)
         {
             const double lq = wave_sum(likq);
             const double ld = wave_sum(log(sprod));
-            const double mn = wave_min(smin);
+            const bool anyneg = __any(sneg < 0);
             lik2 = lik1;
             lik1 = lik;
             lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (lq + ld)) / n_obs;
-            if (mn < 0.0) lik = NAN;   // log of a negative Sigma in the reference
+            if (anyneg) lik = NAN;   // log of a negative Sigma in the reference
         }
         if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
@@ -295,14 +336,16 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
 
         // ------------------------------------------------ B1: compose the reverse affine maps
         double Pi = 1.0, G = 0.0, H = 0.0;
+        auto b1 = [&](int j) {
+            const double J = Jv[j];
+            G = fma(J, G, gv_[j]);
+            H = fma(J * J, H, hv[j]);
+            Pi *= J;
+        };
+        if (act) {
+            if (tail) b1(L - 1);
 #pragma unroll
-        for (int j = L - 1; j >= 0; j--) {
-            if (j < nvalid) {
-                const double J = Jv[j];
-                G = fma(J, G, gv_[j]);
-                H = fma(J * J, H, hv[j]);
-                Pi *= J;
-            }
+            for (int j = L - 2; j >= 0; j--) b1(j);
         }
         // reverse inclusive scan: lane l composes its map after those of lanes > l
 #pragma unroll
@@ -316,61 +359,60 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
                 Pi *= Pb;
             }
         }
-        // Xs at the first step of this lane's chunk; the entry for lane l is lane l+1's value
-        double Xn = fma(Pi, XT, G);
-        double Vn = fma(Pi * Pi, VT, H);
-        Xn = __shfl_down(Xn, 1, 64);
-        Vn = __shfl_down(Vn, 1, 64);
-        if (lane == 63) { Xn = XT; Vn = VT; }
+        // (G, H) = (Xs, Vs) at the first step of this lane's chunk (terminal value is zero);
+        // the entry for lane l is lane l+1's value
+        double Xn = __shfl_down(G, 1, 64);
+        double Vn = __shfl_down(H, 1, 64);
+        if (lane >= lastLane) { Xn = 0.0; Vn = 0.0; }
 
         // ------------------------------------------------ B2: serial reverse re-run + M-step sums
-        double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, termLast = 0.0, term = 0.0;
+        double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, term = 0.0;
         double aSxv[QQ], aTx1u[PP], aTux[PP];
 #pragma unroll
         for (int k = 0; k < QQ; k++) aSxv[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < PP; k++) { aTx1u[k] = 0.0; aTux[k] = 0.0; }
-        double Xs = Xn, Vs = Vn;
+        double Xs = 0.0, Vs = 0.0;
+        auto b2 = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            const double J = Jv[j];
+            Xs = fma(J, Xn, gv_[j]);        // :101
+            Vs = fma(J * J, Vn, hv[j]);     // :102
+            aTx1x = fma(Xn, Xs, fma(Vn, J, aTx1x));   // :180  (zero at t = T-1)
 #pragma unroll
-        for (int j = L - 1; j >= 0; j--) {
-            if (j < nvalid) {
-                const bool o = (obsmask >> j) & 1u;
-                const double J = Jv[j];
-                Xs = fma(J, Xn, gv_[j]);        // :101
-                Vs = fma(J * J, Vn, hv[j]);     // :102
-                if (j != jLast || lane != lastLane)   // pairs (t, t+1) exist for t <= T-2 only
-                    aTx1x = fma(Xn, Xs, fma(Vn, J, aTx1x));   // :180
-#pragma unroll
-                for (int k = 0; k < PP; k++) {
-                    const double ut = us[(j * PP + k) * 64 + lane];   // zero at t = T-1
-                    aTx1u[k] = fma(Xn, ut, aTx1u[k]);                 // :190
-                    aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
-                }
-                term = fma(Xs, Xs, Vs);
-                aPall += term;                                        // :181,:183
-                if (j == jLast) termLast = term;
-                const double xo = o ? Xs : 0.0;
-                aSyx = fma(ys[j * 64 + lane], xo, aSyx);              // :151
-                aSxx += o ? term : 0.0;                               // :152
-#pragma unroll
-                for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
-                Xn = Xs;
-                Vn = Vs;
+            for (int k = 0; k < PP; k++) {
+                const double ut = us[(j * PP + k) * 64 + lane];   // zero at t = T-1
+                aTx1u[k] = fma(Xn, ut, aTx1u[k]);                 // :190
+                aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
             }
+            term = fma(Xs, Xs, Vs);
+            aPall += term;                                        // :181,:183
+            const double xo = o ? Xs : 0.0;
+            aSyx = fma(ys[j * 64 + lane], xo, aSyx);              // :151
+            if (!DENSE) aSxx += o ? term : 0.0;                   // :152
+#pragma unroll
+            for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
+            Xn = Xs;
+            Vn = Vs;
+        };
+        if (act) {
+            if (tail) b2(L - 1);
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2(j);
         }
         Sums<PP, QQ> S;
         S.Syx = wave_sum(aSyx);
-        S.Sxx = wave_sum(aSxx);
         S.Tx1x = wave_sum(aTx1x);
         const double Pall = wave_sum(aPall);
+        S.Sxx = DENSE ? Pall : wave_sum(aSxx);
 #pragma unroll
         for (int k = 0; k < QQ; k++) S.Sxv[k] = wave_sum(aSxv[k]);
 #pragma unroll
         for (int k = 0; k < PP; k++) { S.Tx1u[k] = wave_sum(aTx1u[k]); S.Tux[k] = wave_sum(aTux[k]); }
         S.X0 = readlane_d(Xs, 0);
         S.V0 = readlane_d(Vs, 0);
-        S.Txx = Pall - readlane_d(termLast, lastLane);    // t = 0 .. T-2
-        S.Tx1x1 = Pall - readlane_d(term, 0);             // t = 1 .. T-1
+        S.Txx = Pall - termLast;                  // t = 0 .. T-2
+        S.Tx1x1 = Pall - readlane_d(term, 0);     // t = 1 .. T-1
         mstep_update(th, S, sc, T);
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
@@ -395,7 +437,7 @@ __global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams 
 static inline int scan_wpb(int L, int PP, int QQ) {
     const size_t lds = (size_t)64 * L * (1 + PP + QQ) * sizeof(double);
     const int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int want = (L > 16) ? 4 : 8;       // L = 32 kernels hold one wave per SIMD
+    const int want = (L > 16) ? 4 : 8;       // L > 16 kernels hold one wave per SIMD
     int wpb = (want + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
     if (wpb < 2) wpb = 2;
     if (L <= 16 && wpb < 4 && lds > 20 * 1024) wpb = 4;

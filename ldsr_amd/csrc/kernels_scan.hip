@@ -3,7 +3,13 @@
 #include "em_scan_impl.h"
 #include "ldsr_kernels.h"
 
-static int scan_L_for(int T) { return T <= 64 * 4 ? 4 : T <= 64 * 16 ? 16 : T <= 64 * 32 ? 32 : 0; }
+// smallest compiled chunk length with T <= 64*L; every choice also satisfies L*(L-1) <= T
+static int scan_L_for(int T) {
+    static const int Ls[] = {2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int L : Ls)
+        if (T <= 64 * L) return (T >= L * (L - 1)) ? L : 0;
+    return 0;
+}
 
 bool em_scan_supported(int T, int PP, int QQ) {
     const int L = scan_L_for(T);
@@ -16,8 +22,14 @@ int em_scan_waves_per_block(int T, int PP, int QQ) { return scan_wpb(scan_L_for(
 hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb,
                           hipStream_t stream) {
     switch (scan_L_for(prm.T)) {
+        case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 3: return launch_em_scan_L<3>(prm, PP, QQ, n_blocks, wpb, stream);
         case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 6: return launch_em_scan_L<6>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 8: return launch_em_scan_L<8>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 12: return launch_em_scan_L<12>(prm, PP, QQ, n_blocks, wpb, stream);
         case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 24: return launch_em_scan_L<24>(prm, PP, QQ, n_blocks, wpb, stream);
         case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, stream);
         default: return hipErrorInvalidValue;
     }

@@ -56,6 +56,7 @@ __device__ static bool invert_small(double *a, int n) {
     return true;
 }
 
+#define PREP_TILE 256
 __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     const int s = blockIdx.x;
     const int T = prm.T, p = prm.p, q = prm.q, PP = prm.PP, QQ = prm.QQ;
@@ -68,54 +69,67 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     double *up = prm.up + (prm.shared_uv ? 0 : (long)s * T * PP);
     double *vp = prm.vp + (prm.shared_uv ? 0 : (long)s * T * QQ);
 
-    for (int t = tid; t < T; t += blockDim.x) yp[t] = y[t];
-    if (own_uv) {
-        for (int i = tid; i < T * PP; i += blockDim.x) {
-            const int t = i / PP, k = i - t * PP;
-            up[i] = (u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;  // u[:,T-1] is never read (src/EM.cpp:74,190-193)
-        }
-        for (int i = tid; i < T * QQ; i += blockDim.x) {
-            const int t = i / QQ, k = i - t * QQ;
-            vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
-        }
-    }
+    // The series is streamed through LDS in tiles of PREP_TILE steps (coalesced loads); each of
+    // the 138 statistics is owned by one thread and summed in ascending t like the reference.
+    __shared__ double ty[PREP_TILE], tu[PREP_TILE * LDSR_MAXPQ], tv[PREP_TILE * LDSR_MAXPQ];
     __shared__ SeriesConst sc;
-    // one matrix / vector entry per thread, sequential (ascending t) sums like the reference
-    if (tid < 64) {
-        const int k = tid >> 3, l = tid & 7;
-        double a = (k == l) ? 1.0 : 0.0;
-        if (v && k < q && l < q) {
-            a = 0.0;
-            for (int t = 0; t < T; t++)
-                if (isfinite(y[t])) a += v[(long)t * q + k] * v[(long)t * q + l];
+    // role of this thread
+    const int role = tid < 64 ? 0 : tid < 128 ? 1 : tid < 136 ? 2 : tid == 136 ? 3 : 4;
+    const int k = (role == 2) ? tid - 128 : ((tid & 63) >> 3), l = tid & 7;
+    double acc = 0.0;
+    int n = 0, first = -1, last = -1;
+    const bool live = (role == 0 && v && k < q && l < q) || (role == 1 && u && k < p && l < p) ||
+                      (role == 2 && v && k < q) || role == 3;
+    for (int tb = 0; tb < T; tb += PREP_TILE) {
+        const int nt = min(PREP_TILE, T - tb);
+        for (int i = tid; i < nt; i += 256) {
+            const double yv = y[tb + i];
+            ty[i] = yv;
+            yp[tb + i] = yv;
         }
-        sc.Svv_inv[k * LDSR_MAXPQ + l] = a;
-    } else if (tid < 128) {
-        const int k = (tid - 64) >> 3, l = tid & 7;
-        double a = (k == l) ? 1.0 : 0.0;
-        if (u && k < p && l < p) {
-            a = 0.0;
-            for (int t = 0; t < T - 1; t++) a += u[(long)t * p + k] * u[(long)t * p + l];
-        }
-        sc.Tuu_inv[k * LDSR_MAXPQ + l] = a;
-    } else if (tid < 136) {
-        const int k = tid - 128;
-        double a = 0.0;
-        if (v && k < q)
-            for (int t = 0; t < T; t++)
-                if (isfinite(y[t])) a += y[t] * v[(long)t * q + k];
-        sc.Syv[k] = a;
-    } else if (tid == 136) {
-        double a = 0.0;
-        int n = 0, first = -1, last = -1;
-        for (int t = 0; t < T; t++)
-            if (isfinite(y[t])) {
-                a += y[t] * y[t];
-                n++;
-                if (first < 0) first = t;
-                last = t;
+        if (u)
+            for (int i = tid; i < nt * p; i += 256) tu[i] = u[(long)tb * p + i];
+        if (v)
+            for (int i = tid; i < nt * q; i += 256) tv[i] = v[(long)tb * q + i];
+        __syncthreads();
+        if (own_uv) {
+            for (int i = tid; i < nt * PP; i += 256) {
+                const int tt = i / PP, kk = i - tt * PP;
+                // u[:,T-1] is never read by the reference (src/EM.cpp:74,190-193): zero it
+                up[(long)tb * PP + i] = (u && kk < p && tb + tt < T - 1) ? tu[tt * p + kk] : 0.0;
             }
-        sc.Syy = a;
+            for (int i = tid; i < nt * QQ; i += 256) {
+                const int tt = i / QQ, kk = i - tt * QQ;
+                vp[(long)tb * QQ + i] = (v && kk < q) ? tv[tt * q + kk] : 0.0;
+            }
+        }
+        if (live) {
+            if (role == 0) {
+                for (int tt = 0; tt < nt; tt++)
+                    if (isfinite(ty[tt])) acc += tv[tt * q + k] * tv[tt * q + l];
+            } else if (role == 1) {
+                const int ne = min(nt, T - 1 - tb);
+                for (int tt = 0; tt < ne; tt++) acc += tu[tt * p + k] * tu[tt * p + l];
+            } else if (role == 2) {
+                for (int tt = 0; tt < nt; tt++)
+                    if (isfinite(ty[tt])) acc += ty[tt] * tv[tt * q + k];
+            } else {
+                for (int tt = 0; tt < nt; tt++)
+                    if (isfinite(ty[tt])) {
+                        acc += ty[tt] * ty[tt];
+                        n++;
+                        if (first < 0) first = tb + tt;
+                        last = tb + tt;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (role == 0) sc.Svv_inv[k * LDSR_MAXPQ + l] = live ? acc : (k == l ? 1.0 : 0.0);
+    if (role == 1) sc.Tuu_inv[k * LDSR_MAXPQ + l] = live ? acc : (k == l ? 1.0 : 0.0);
+    if (role == 2) sc.Syv[k] = live ? acc : 0.0;
+    if (role == 3) {
+        sc.Syy = acc;
         sc.n_obs = n;
         sc.t_first_obs = first;
         sc.t_last_obs = last;
@@ -126,10 +140,10 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
         if (v) ok = invert_small(sc.Svv_inv, q) && ok;
         if (u) ok = invert_small(sc.Tuu_inv, p) && ok;
         sc.status = ok ? 0 : 2;
-        for (int k = 0; k < LDSR_MAXPQ; k++) {
+        for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
             double a = 0.0;
-            for (int l = 0; l < LDSR_MAXPQ; l++) a += sc.Svv_inv[k * LDSR_MAXPQ + l] * sc.Syv[l];
-            sc.wv[k] = a;
+            for (int ll = 0; ll < LDSR_MAXPQ; ll++) a += sc.Svv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];
+            sc.wv[kk] = a;
         }
         prm.sc[s] = sc;
     }
