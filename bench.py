@@ -114,13 +114,16 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from ldsr_amd import _lib, synth
+    from ldsr_amd import _lib, shard, synth
     L = _lib.lib()
 
     T, p, q, cells, niter = WORKLOADS[args.workload]
     P = 6 + p + q
     y, u, v = synth.make_series(T, p, q, series_id=0, mask=args.mask)
-    th0 = synth.make_init_packed(p, q, cells, seed=1, first=rank * cells)
+    # global restart grid = world x cells restarts of one series; this rank's contiguous slice
+    lo, hi = shard.rank_slice(world * cells, world, rank)
+    assert hi - lo == cells
+    th0 = synth.make_init_packed(p, q, cells, seed=1, first=lo)
 
     d_y = torch.from_numpy(y).to(dev)
     d_u = torch.from_numpy(np.ascontiguousarray(u.T)).to(dev)       # [T][p]

@@ -1,0 +1,42 @@
+/* Minimal DECLARATIONS of the R C API used by ldsr_amd/r_shim/ldsrhip_call.c, for a
+ * syntax-only compile check (tests/test_r_shim_syntax.py).  R is not installed in this image;
+ * nothing here is linked or run, and this is not a substitute for testing under R. */
+#ifndef R_STUB_RINTERNALS_H
+#define R_STUB_RINTERNALS_H
+#include <stddef.h>
+typedef struct SEXPREC *SEXP;
+typedef ptrdiff_t R_xlen_t;
+typedef void *(*DL_FUNC)(void);
+#define REALSXP 14
+#define INTSXP 13
+#define STRSXP 16
+#define VECSXP 19
+extern SEXP R_NilValue, R_NamesSymbol;
+SEXP Rf_getAttrib(SEXP, SEXP);
+SEXP Rf_setAttrib(SEXP, SEXP, SEXP);
+R_xlen_t Rf_xlength(SEXP);
+SEXP STRING_ELT(SEXP, R_xlen_t);
+SEXP VECTOR_ELT(SEXP, R_xlen_t);
+SEXP SET_VECTOR_ELT(SEXP, R_xlen_t, SEXP);
+void SET_STRING_ELT(SEXP, R_xlen_t, SEXP);
+const char *CHAR(SEXP);
+SEXP Rf_mkChar(const char *);
+SEXP Rf_allocVector(unsigned int, R_xlen_t);
+SEXP Rf_allocMatrix(unsigned int, int, int);
+double *REAL(SEXP);
+int *INTEGER(SEXP);
+int Rf_isReal(SEXP);
+int Rf_ncols(SEXP);
+int Rf_nrows(SEXP);
+int Rf_asInteger(SEXP);
+double Rf_asReal(SEXP);
+SEXP Rf_ScalarReal(double);
+SEXP Rf_ScalarInteger(int);
+SEXP Rf_protect(SEXP);
+void Rf_unprotect(int);
+#define PROTECT(s) Rf_protect(s)
+#define UNPROTECT(n) Rf_unprotect(n)
+void Rf_error(const char *, ...);
+char *R_alloc(size_t, int);
+void R_CheckUserInterrupt(void);
+#endif

@@ -1,0 +1,133 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol that include/ldsr_hip.h
+declares, argument errors surface with messages, the product path refuses to run without a GPU
+(no CPU fallback), and host-side helpers behave like the reference's R code."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ldsr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldsr_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ldsr_amd import _lib
+    assert os.path.exists(_lib.SO_PATH), "run __graft_entry__.build() first"
+    names = _declared_symbols()
+    assert len(names) >= 12
+    L = C.CDLL(_lib.SO_PATH)
+    for n in names:
+        assert hasattr(L, n), "missing symbol %s" % n
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert b"gfx950" in _lib.lib().ldsr_version()
+
+
+def test_code_object_is_gfx950_only():
+    from ldsr_amd import _lib
+    blob = open(_lib.SO_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    assert b"gfx942" not in blob and b"gfx90a" not in blob
+
+
+def test_argument_validation_without_gpu():
+    from ldsr_amd import _lib
+    L = _lib.lib()
+    dp = C.POINTER(C.c_double)
+    y = (C.c_double * 4)(0, 1, 2, 3)
+    off = (C.c_int * 2)(0, 1)
+    th = (C.c_double * 8)()
+    out = (C.c_double * 8)()
+    lik = (C.c_double * 1)()
+    it = (C.c_int * 1)()
+    st = (C.c_int * 1)()
+    # T < 2
+    rc = L.ldsr_em_batch(0, 1, 1, 1, 1, y, None, None, 0, off, th, 10, 1e-5, 0, out, lik, it, st, None)
+    assert rc == 1 and b"T must be" in L.ldsr_last_error()
+    # p > 8
+    rc = L.ldsr_em_batch(0, 1, 4, 9, 1, y, None, None, 0, off, th, 10, 1e-5, 0, out, lik, it, st, None)
+    assert rc == 2
+    # niter < 2: the reference reads lik[1] unconditionally (src/EM.cpp:256)
+    rc = L.ldsr_em_batch(0, 1, 4, 1, 1, y, None, None, 0, off, th, 1, 1e-5, 0, out, lik, it, st, None)
+    assert rc == 1 and b"niter" in L.ldsr_last_error()
+    # bad offsets
+    bad = (C.c_int * 2)(1, 1)
+    rc = L.ldsr_em_batch(0, 1, 4, 1, 1, y, None, None, 0, bad, th, 10, 1e-5, 0, out, lik, it, st, None)
+    assert rc == 1
+    assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 0) > 0
+    assert L.ldsr_em_workspace_bytes(1, 1000, 9, 2, 4096, 0) == 0
+    # serial needs the [t][cell] strip, scan does not
+    assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 1) >= 2 * 1000 * 4096 * 8
+    assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 2) < 1 << 20
+    assert L.ldsr_em_workspace_bytes(1, 5000, 1, 2, 64, 2) == 0     # scan kernel: T <= 2048
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import ldsr_amd
+    from ldsr_amd import _lib, synth
+    if _lib.lib().ldsr_device_count() > 0:
+        pytest.skip("GPU present")
+    y, u, v = synth.make_series(50, 1, 2)
+    with pytest.raises(_lib.LdsrError):
+        ldsr_amd.em_batch(y, u, v, synth.make_init_packed(1, 2, 2), niter=5)
+    with pytest.raises(_lib.LdsrError):
+        ldsr_amd.Kalman_smoother(y, u, v, synth.make_init_packed(1, 2, 1)[0])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ldsr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc", ".c", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|oracle/|libldsr_oracle", src,
+                                     flags=re.M), "%s uses the oracle" % os.path.join(dirpath, f)
+
+
+def test_select_restart_matches_reference_rule():
+    """R/LDS_reconstruction.R:50-58 through the C ABI (host-only function)."""
+    import ldsr_amd
+    p, q = 1, 2
+    th = np.zeros((4, 9))
+    th[:, 2] = [0.5, -0.2, 0.1, 0.3]                 # C
+    assert ldsr_amd.select_restart([1.0, 9.0, 3.0, np.nan], th, p, q) == 2
+    th[:, 2] = -1.0
+    assert ldsr_amd.select_restart([1.0, 9.0, 3.0, np.nan], th, p, q) == 1
+    assert ldsr_amd.select_restart([np.nan] * 4, th, p, q) == -1
+
+
+def test_make_init_distribution():
+    """R/LDS_reconstruction.R:14-30: A,C ~ U(0,1); B,D ~ U(-1,1); Q=R=V1=1; mu1=0."""
+    import ldsr_amd
+    init = ldsr_amd.make_init(3, 2, 2000, seed=123)
+    assert len(init) == 2000 and init[0]["B"].shape == (1, 3) and init[0]["D"].shape == (1, 2)
+    A = np.array([t["A"][0, 0] for t in init])
+    B = np.concatenate([t["B"].ravel() for t in init])
+    Cc = np.array([t["C"][0, 0] for t in init])
+    D = np.concatenate([t["D"].ravel() for t in init])
+    assert 0 <= A.min() and A.max() < 1 and abs(A.mean() - 0.5) < 0.03
+    assert 0 <= Cc.min() and Cc.max() < 1 and abs(Cc.mean() - 0.5) < 0.03
+    assert -1 <= B.min() and B.max() < 1 and abs(B.mean()) < 0.04 and B.min() < -0.9
+    assert -1 <= D.min() and D.max() < 1 and abs(D.mean()) < 0.04
+    assert all(t["Q"][0, 0] == 1 and t["R"][0, 0] == 1 and t["mu1"][0, 0] == 0
+               and t["V1"][0, 0] == 1 for t in init)
+    th = ldsr_amd.pack_theta(init[0], 3, 2)
+    back = ldsr_amd.unpack_theta(th, 3, 2)
+    assert all(np.array_equal(back[k], init[0][k]) for k in back)
+
+
+def test_synthetic_generator_is_shard_independent():
+    from ldsr_amd import synth
+    a = synth.make_init_packed(1, 2, 100, seed=1)
+    b = synth.make_init_packed(1, 2, 40, seed=1, first=60)
+    assert np.array_equal(a[60:], b)
+    y, u, v = synth.make_series(300, 1, 2, mask="paleo")
+    assert np.isnan(y[:270]).all() and np.isfinite(y[270:]).all()
+    assert abs(np.nanmean(y)) < 1e-12

@@ -1,0 +1,104 @@
+"""Multi-GPU host path on CPU: two gloo ranks shard a (series, restart) grid, each computes
+its slice (the CPU oracle stands in for the GPU engine here -- the sharding, gather and
+selection logic is what is under test) and every rank must end up with exactly the
+single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _oracle_compute(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5):
+    from oracle import oracle as O
+    Y = np.atleast_2d(np.asarray(y))
+    S = Y.shape[0]
+
+    def tm(a):
+        if a is None:
+            return None
+        a = np.asarray(a)
+        if a.ndim == 2:
+            a = np.repeat(a[None], S, axis=0)
+        return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+    off = np.asarray(cell_offsets)
+    soc = np.repeat(np.arange(S), np.diff(off)).astype(np.int32)
+    th, lik, nit, st = O.em_batch(Y, tm(u), tm(v), soc, theta0, niter, tol, n_threads=2)
+    return {"theta": th, "lik": lik, "n_iter": nit, "status": st}
+
+
+def _problem():
+    from ldsr_amd import synth
+    T, p, q, S = 120, 1, 2, 3
+    ys, us, vs = zip(*[synth.make_series(T, p, q, series_id=40 + s, mask="paleo", n_tail=60)
+                       for s in range(S)])
+    counts = [5, 2, 6]                      # ragged; 13 cells do not split evenly over 2 ranks
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    th0 = synth.make_init_packed(p, q, int(off[-1]), seed=9)
+    return np.stack(ys), np.stack(us), np.stack(vs), th0, off, p, q
+
+
+def _worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from ldsr_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Y, U, V, th0, off, p, q = _problem()
+        r = shard.em_batch_sharded(Y, U, V, th0, cell_offsets=off, niter=40, tol=1e-5,
+                                   compute=_oracle_compute)
+        q_out.put((rank, r))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    import torch.multiprocessing as mp
+
+    from ldsr_amd import shard
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    got = dict(q_out.get(timeout=120) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    Y, U, V, th0, off, p, q = _problem()
+    ref = _oracle_compute(Y, U, V, th0, cell_offsets=off, niter=40, tol=1e-5)
+    for rank in (0, 1):
+        for k in ("theta", "lik", "n_iter", "status"):
+            assert np.array_equal(got[rank][k], ref[k], equal_nan=True), (rank, k)
+    win = shard.select_per_series(ref["lik"], ref["theta"], off, p, q,
+                                  select=lambda l, t, p_, q_: O.select(l, t[:, 1 + p_]))
+    assert win.shape == (3,) and np.all(win >= 0)
+    for s in range(3):
+        assert off[s] <= win[s] < off[s + 1]
+
+
+def test_rank_slices_cover_grid_exactly():
+    from ldsr_amd import shard
+    for n in (0, 1, 7, 4096, 24576):
+        for world in (1, 2, 3, 8):
+            edges = [shard.rank_slice(n, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+    keep, loc = shard.local_offsets([0, 5, 5, 9, 12], 3, 10)
+    assert keep.tolist() == [0, 2, 3] and loc.tolist() == [0, 2, 6, 7]
