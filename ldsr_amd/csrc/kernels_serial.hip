@@ -104,23 +104,33 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             }
         }
         if (live) {
+            // branch-free bodies so the LDS reads of successive steps pipeline
             if (role == 0) {
-                for (int tt = 0; tt < nt; tt++)
-                    if (isfinite(ty[tt])) acc += tv[tt * q + k] * tv[tt * q + l];
+#pragma unroll 8
+                for (int tt = 0; tt < nt; tt++) {
+                    const double pr = tv[tt * q + k] * tv[tt * q + l];
+                    acc += isfinite(ty[tt]) ? pr : 0.0;
+                }
             } else if (role == 1) {
                 const int ne = min(nt, T - 1 - tb);
+#pragma unroll 8
                 for (int tt = 0; tt < ne; tt++) acc += tu[tt * p + k] * tu[tt * p + l];
             } else if (role == 2) {
-                for (int tt = 0; tt < nt; tt++)
-                    if (isfinite(ty[tt])) acc += ty[tt] * tv[tt * q + k];
+#pragma unroll 8
+                for (int tt = 0; tt < nt; tt++) {
+                    const double yv = ty[tt];
+                    acc += isfinite(yv) ? yv * tv[tt * q + k] : 0.0;
+                }
             } else {
-                for (int tt = 0; tt < nt; tt++)
-                    if (isfinite(ty[tt])) {
-                        acc += ty[tt] * ty[tt];
-                        n++;
-                        if (first < 0) first = tb + tt;
-                        last = tb + tt;
-                    }
+#pragma unroll 8
+                for (int tt = 0; tt < nt; tt++) {
+                    const double yv = ty[tt];
+                    const bool o = isfinite(yv);
+                    acc += o ? yv * yv : 0.0;
+                    n += o ? 1 : 0;
+                    first = (o && first < 0) ? tb + tt : first;
+                    last = o ? tb + tt : last;
+                }
             }
         }
         __syncthreads();
