@@ -12,11 +12,12 @@
 //
 //  forward (:70-90)   The joint filter state is carried in projective coordinates
 //                     (n, d, xt) with Vp = n/d, Xp = xt/d.  One time step is LINEAR in them:
-//                         n'  = (A^2 R + Q c^2) n + (Q R) d
-//                         d'  =          c^2  n +     R d
-//                         xt' = (A c e + bu c^2) n + (bu R) d + (A R) xt
-//                     with c = C on observed steps and 0 on missing ones, e = y - D v,
-//                     bu = B u.  (F1) every lane multiplies its L step matrices;
+//                         n'  = (A^2 + Q c^2/R) n + Q d
+//                         d'  =        (c^2/R) n +   d
+//                         xt' = ((A c/R) e + bu c^2/R) n + bu d + A xt
+//                     (the matrix of the filter step divided by R: projective coordinates
+//                     are scale free) with c = C on observed steps and 0 on missing ones,
+//                     e = y - D v, bu = B u.  (F1) every lane multiplies its L step matrices;
 //                     (scan) a 64-lane inclusive scan composes them; (F2) every lane re-runs
 //                     its L steps serially from its exact entry state with the reference's
 //                     own expressions and keeps J_t, g_t = Xu_t - J_t Xp_{t+1},
@@ -60,6 +61,22 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
+// All-reduce N independent sums with ONE dependent chain of 6 cross-lane rounds: every round
+// issues all N exchanges before the N adds (a per-value butterfly would serialise 6*N LDS
+// round-trips).  The summation tree is fixed, so results are run-to-run deterministic and
+// identical in every lane (fp add is commutative).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        double t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = __shfl_xor(x[i], d, 64);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += t[i];
+    }
+}
+
 __device__ __forceinline__ double wave_min(double x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x = fmin(x, __shfl_xor(x, d, 64));
@@ -81,6 +98,20 @@ __device__ __forceinline__ PMat pmul(const PMat &a, const PMat &b) {
     r.m20 = fma(a.m20, b.m00, fma(a.m21, b.m10, a.m22 * b.m20));
     r.m21 = fma(a.m20, b.m01, fma(a.m21, b.m11, a.m22 * b.m21));
     r.m22 = a.m22 * b.m22;
+    return r;
+}
+
+// r = S * b for a step matrix S = [[a00 Q 0],[g 1 0],[s20 bu A]]  (13 flops)
+__device__ __forceinline__ PMat pstep(double a00, double Q, double g, double s20, double bu, double A,
+                                      const PMat &b) {
+    PMat r;
+    r.m00 = fma(a00, b.m00, Q * b.m10);
+    r.m01 = fma(a00, b.m01, Q * b.m11);
+    r.m10 = fma(g, b.m00, b.m10);
+    r.m11 = fma(g, b.m01, b.m11);
+    r.m20 = fma(s20, b.m00, fma(bu, b.m10, A * b.m20));
+    r.m21 = fma(s20, b.m01, fma(bu, b.m11, A * b.m21));
+    r.m22 = A * b.m22;
     return r;
 }
 
@@ -214,8 +245,9 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     for (;;) {
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
-        const double A2 = A * A, C2 = C * C, AR = A * R, AC = A * C, QR = Q * R;
-        const double A2R = A2 * R, alpha = fma(Q, C2, A2R);
+        const double A2 = A * A, C2 = C * C;
+        const double rR = 1.0 / R;
+        const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
 
         // ------------------------------------------------ F1: compose this lane's step matrices
         PMat M;
@@ -228,16 +260,15 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             double bu = 0.0;
 #pragma unroll
             for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
-            PMat S;
-            S.m00 = o ? alpha : A2R;
-            S.m01 = QR;
-            S.m10 = o ? C2 : 0.0;
-            S.m11 = R;
-            S.m20 = o ? fma(bu, C2, AC * e) : 0.0;
-            S.m21 = bu * R;
-            S.m22 = AR;
-            if (j == 0) M = S; else M = pmul(S, M);
-            if ((j & 7) == 7 && j < L - 2) prenorm(M);
+            const double a00 = o ? alpha : A2;
+            const double g = o ? C2R : 0.0;
+            const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
+            if (j == 0) {
+                M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
+            } else {
+                M = pstep(a00, Q, g, s20, bu, A, M);
+            }
+            if ((j & 15) == 15 && j < L - 2) prenorm(M);
         };
         if (act) {
 #pragma unroll
@@ -248,15 +279,27 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
         // ------------------------------------------------ forward scan (inclusive, by lane)
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
+        for (int d = 1; d < 32; d <<= 1) {
             const PMat Pm = pshfl_up(M, d);
             if (lane >= d) M = pmul(M, Pm);
-            if (d == 4 || d == 32) prenorm(M);
+            if (d == 4) prenorm(M);
         }
-        // state after this lane's chunk, then shift by one lane to get the entry state
+        // M now composes lanes max(0, l-31) .. l.  State after this lane's chunk: lanes < 32
+        // apply M to the initial state; lanes >= 32 apply it to the state of lane l-32 (a
+        // matrix-vector product instead of a sixth matrix-matrix round).
         double n_e = fma(M.m00, th.V1, M.m01);
         double d_e = fma(M.m10, th.V1, M.m11);
         double x_e = fma(M.m20, th.V1, fma(M.m22, th.mu1, M.m21));
+        {
+            const double n_b = __shfl_up(n_e, 32, 64), d_b = __shfl_up(d_e, 32, 64),
+                         x_b = __shfl_up(x_e, 32, 64);
+            if (lane >= 32) {
+                n_e = fma(M.m00, n_b, M.m01 * d_b);
+                d_e = fma(M.m10, n_b, M.m11 * d_b);
+                x_e = fma(M.m20, n_b, fma(M.m21, d_b, M.m22 * x_b));
+            }
+        }
+        // shift by one lane: the entry state of lane l is the exit state of lane l-1
         n_e = __shfl_up(n_e, 1, 64);
         d_e = __shfl_up(d_e, 1, 64);
         x_e = __shfl_up(x_e, 1, 64);
@@ -286,7 +329,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             sneg |= __double2hiint(sl);
             const double w = Vp * r;
             const double K = C * w;                    // :86
-            Vu = fma(-(C2 * w), Vp, Vp);               // (1 - K C) Vp  :88
+            if (DENSE) Vu = R * w;                     // (1 - K C) Vp = R Vp / Sigma   :88
+            else Vu = fma(-(C2 * w), Vp, Vp);
             const double dl = fma(-C, Xp, e);          // y - Yp
             Xu = fma(K, dl, Xp);                       // :87
             likq = fma(dl * r, dl, likq);              // delta/Sigma*delta  :122
@@ -320,19 +364,18 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
         // likelihood (:113-124)
         {
-            const double lq = wave_sum(likq);
-            const double ld = wave_sum(log(sprod));
-            const bool anyneg = __any(sneg < 0);
+            double l2[2] = {likq, log(sprod)};
+            wave_sum_n<2>(l2);
             lik2 = lik1;
             lik1 = lik;
-            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (lq + ld)) / n_obs;
-            if (anyneg) lik = NAN;   // log of a negative Sigma in the reference
+            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (l2[0] + l2[1])) / n_obs;
+            if (__any(sneg < 0)) lik = NAN;   // log of a negative Sigma in the reference
         }
         if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
         bool stop = it >= prm.niter;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
-        if (__builtin_amdgcn_readfirstlane((int)stop)) break;
+        if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
 
         // ------------------------------------------------ B1: compose the reverse affine maps
         double Pi = 1.0, G = 0.0, H = 0.0;
@@ -401,18 +444,28 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             for (int j = L - 2; j >= 0; j--) b2(j);
         }
         Sums<PP, QQ> S;
-        S.Syx = wave_sum(aSyx);
-        S.Tx1x = wave_sum(aTx1x);
-        const double Pall = wave_sum(aPall);
-        S.Sxx = DENSE ? Pall : wave_sum(aSxx);
+        {
+            constexpr int NR = 3 + (DENSE ? 0 : 1) + QQ + 2 * PP;
+            double red[NR];
+            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall;
+            if (!DENSE) red[3] = aSxx;
+            constexpr int o0 = 3 + (DENSE ? 0 : 1);
 #pragma unroll
-        for (int k = 0; k < QQ; k++) S.Sxv[k] = wave_sum(aSxv[k]);
+            for (int k = 0; k < QQ; k++) red[o0 + k] = aSxv[k];
 #pragma unroll
-        for (int k = 0; k < PP; k++) { S.Tx1u[k] = wave_sum(aTx1u[k]); S.Tux[k] = wave_sum(aTux[k]); }
-        S.X0 = readlane_d(Xs, 0);
-        S.V0 = readlane_d(Vs, 0);
-        S.Txx = Pall - termLast;                  // t = 0 .. T-2
-        S.Tx1x1 = Pall - readlane_d(term, 0);     // t = 1 .. T-1
+            for (int k = 0; k < PP; k++) { red[o0 + QQ + k] = aTx1u[k]; red[o0 + QQ + PP + k] = aTux[k]; }
+            wave_sum_n<NR>(red);
+            S.Syx = red[0]; S.Tx1x = red[1];
+            S.Sxx = DENSE ? red[2] : red[3];
+#pragma unroll
+            for (int k = 0; k < QQ; k++) S.Sxv[k] = red[o0 + k];
+#pragma unroll
+            for (int k = 0; k < PP; k++) { S.Tx1u[k] = red[o0 + QQ + k]; S.Tux[k] = red[o0 + QQ + PP + k]; }
+            S.Txx = red[2] - termLast;                  // t = 0 .. T-2
+            S.Tx1x1 = red[2] - readlane_d(term, 0);     // t = 1 .. T-1
+        }
+        S.X0 = readlane_d(Xs, 0);                       // :218
+        S.V0 = readlane_d(Vs, 0);                       // :219
         mstep_update(th, S, sc, T);
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
