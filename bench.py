@@ -5,11 +5,12 @@ One "step" = one pass of the hot path over one batch: a single ldsr_em_batch_dev
 (series preparation + the EM kernel) on BASELINE.json's config 2 -- synthetic T=1000, p=1,
 q=2, 4096 restarts per GPU, niter=100, tol=0 (the stop rule of src/EM.cpp:272 can never fire,
 so every cell runs exactly 100 E-steps) = 409 600 restart x EM-iteration units per GPU.
-Inputs (y, u, v, theta0) are resident in HBM before the timed region.
+Inputs (y, u, v, theta0) are resident in HBM before the timed region.  --workload selects the
+other BASELINE configs (cfg3 per GPU; cfg4 / cfg5 fixed grids) for DESIGN.md's table.
 
 N > 1 (launched by torch.distributed.run): restarts shard embarrassingly -- every rank runs
-its own 4096 restarts of the same series (restart index = rank*4096 + i in the counter-based
-generator), no data-path collective; "scaling": "weak".
+its own 4096 restarts of the same series (restart index = global position in the counter-based
+generator), no data-path collective; "scaling": "weak" (cfg4 / cfg5: "strong").
 
 Prints ONE JSON line on rank 0; see the task contract for the fields.  Extra objects:
   roofline      algorithmic bytes (16*T*(3+p+q) per unit) / EM-kernel time
@@ -29,11 +30,60 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+# BASELINE.json configs.  cfg2 (the metric's config) and cfg3 are quoted per GPU -> weak scaling
+# (every rank gets `restarts` restarts of the one series); cfg4 / cfg5 are fixed grids "sharded
+# across the GPUs" -> strong scaling (the grid is cut into contiguous per-rank slices).
 WORKLOADS = {
-    # name: (T, p, q, cells per GPU, niter)
-    "cfg2": (1000, 1, 2, 4096, 100),
-    "cfg3": (1000, 4, 8, 8192, 100),
+    "cfg2": dict(T=1000, p=1, q=2, series=1, restarts=4096, niter=100, scaling="weak"),
+    "cfg3": dict(T=1000, p=4, q=8, series=1, restarts=8192, niter=100, scaling="weak"),
+    "cfg4": dict(T=2000, p=1, q=4, series=10, restarts=1024, niter=100, scaling="strong",
+                 kind="cvfolds"),      # 10 CV folds of one series: shared u, v; own NA mask
+    "cfg5": dict(T=813, p=1, q=3, series=48, restarts=512, niter=100, scaling="strong",
+                 kind="stations"),     # 48 independent series, observed tail of 30..90 steps
 }
+
+
+def build_problem(name, mask, world, rank):
+    """Host arrays of this rank's slice of the workload's (series, restart) grid:
+    Y [S,T], U [S or 1,T,p], V [S or 1,T,q] (time-major), shared_uv, cell_offsets [S+1],
+    theta0 [cells, P], plus the global cell count."""
+    from ldsr_amd import shard, synth
+    w = WORKLOADS[name]
+    T, p, q, S, R = w["T"], w["p"], w["q"], w["series"], w["restarts"]
+    kind = w.get("kind", "single")
+    if kind == "single":
+        y, u, v = synth.make_series(T, p, q, series_id=0, mask=mask)
+        n_global = world * R                       # weak: R restarts per rank
+        lo, hi = shard.rank_slice(n_global, world, rank)
+        th0 = synth.make_init_packed(p, q, hi - lo, seed=1, first=lo)
+        return (y[None], np.ascontiguousarray(u.T[None]), np.ascontiguousarray(v.T[None]), 0,
+                np.array([0, hi - lo], np.int32), th0, n_global)
+    if kind == "cvfolds":
+        # cvLDS (R/LDS_reconstruction.R:270-285): instrumental period = last 200 steps, fold k
+        # hides a contiguous block of 21 instrumental points (make_Z blocks, R/utils.R:89-96)
+        y, u, v = synth.make_series(T, p, q, series_id=4, mask="paleo", n_tail=200)
+        Y = np.repeat(y[None], S, axis=0)
+        for k in range(S):
+            Y[k, T - 200 + 18 * k:T - 200 + 18 * k + 21] = np.nan
+        U, V, shared = np.ascontiguousarray(u.T[None]), np.ascontiguousarray(v.T[None]), 1
+    else:
+        ys, us, vs = zip(*[synth.make_series(T, p, q, series_id=500 + s_, mask="paleo",
+                                             n_tail=30 + (s_ * 60) // max(S - 1, 1))
+                           for s_ in range(S)])
+        Y = np.stack(ys)
+        U = np.ascontiguousarray(np.stack([a.T for a in us]))
+        V = np.ascontiguousarray(np.stack([a.T for a in vs]))
+        shared = 0
+    off = (np.arange(S + 1) * R).astype(np.int64)
+    n_global = int(off[-1])
+    lo, hi = shard.rank_slice(n_global, world, rank)
+    keep, loc = shard.local_offsets(off, lo, hi)
+    th0 = synth.make_init_packed(p, q, hi - lo, seed=1, first=lo)
+    Yk = np.ascontiguousarray(Y[keep])
+    if not shared:
+        U, V = np.ascontiguousarray(U[keep]), np.ascontiguousarray(V[keep])
+    return Yk, U, V, shared, loc, th0, n_global
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -117,33 +167,32 @@ def main():
     from ldsr_amd import _lib, shard, synth
     L = _lib.lib()
 
-    T, p, q, cells, niter = WORKLOADS[args.workload]
+    w = WORKLOADS[args.workload]
+    T, p, q, niter = w["T"], w["p"], w["q"], w["niter"]
     P = 6 + p + q
-    y, u, v = synth.make_series(T, p, q, series_id=0, mask=args.mask)
-    # global restart grid = world x cells restarts of one series; this rank's contiguous slice
-    lo, hi = shard.rank_slice(world * cells, world, rank)
-    assert hi - lo == cells
-    th0 = synth.make_init_packed(p, q, cells, seed=1, first=lo)
+    Y, U, V, shared_uv, loc_off, th0, n_global = build_problem(args.workload, args.mask, world, rank)
+    S_loc = Y.shape[0]
+    cells = th0.shape[0]
 
-    d_y = torch.from_numpy(y).to(dev)
-    d_u = torch.from_numpy(np.ascontiguousarray(u.T)).to(dev)       # [T][p]
-    d_v = torch.from_numpy(np.ascontiguousarray(v.T)).to(dev)       # [T][q]
+    d_y = torch.from_numpy(Y).to(dev)          # [S][T]
+    d_u = torch.from_numpy(U).to(dev)          # [S or 1][T][p]
+    d_v = torch.from_numpy(V).to(dev)          # [S or 1][T][q]
     d_th0 = torch.from_numpy(th0).to(dev)
     d_th = torch.empty_like(d_th0)
     d_lik = torch.empty(cells, dtype=torch.float64, device=dev)
     d_nit = torch.empty(cells, dtype=torch.int32, device=dev)
     d_st = torch.empty(cells, dtype=torch.int32, device=dev)
-    wsb = L.ldsr_em_workspace_bytes(1, T, p, q, cells, args.algo)
+    wsb = L.ldsr_em_workspace_bytes(S_loc, T, p, q, cells, args.algo)
     assert wsb > 0
     d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (d_ws.data_ptr() + 255) & ~255
-    off = (C.c_int * 2)(0, cells)
+    off = (C.c_int * (S_loc + 1))(*[int(x) for x in loc_off])
     stream = torch.cuda.current_stream(dev)
 
     def step():
         _lib.check(L.ldsr_em_batch_device(
-            local_rank, C.c_void_p(stream.cuda_stream), 1, T, p, q, d_y.data_ptr(),
-            d_u.data_ptr(), d_v.data_ptr(), 0, off, d_th0.data_ptr(), niter, 0.0, args.algo,
+            local_rank, C.c_void_p(stream.cuda_stream), S_loc, T, p, q, d_y.data_ptr(),
+            d_u.data_ptr(), d_v.data_ptr(), shared_uv, off, d_th0.data_ptr(), niter, 0.0, args.algo,
             d_th.data_ptr(), d_lik.data_ptr(), d_nit.data_ptr(), d_st.data_ptr(), None,
             C.c_void_p(ws_ptr), wsb))
 
@@ -179,7 +228,7 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        units_per_step = cells * niter * world
+        units_per_step = n_global * niter
         value = units_per_step * args.steps / dt
         kern_ms = tot_ms.value / max(n_l.value, 1)
         bpu = bytes_per_unit(T, p, q)
@@ -189,13 +238,16 @@ def main():
             "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
             "value": value, "unit": "restart*EM-iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": w["scaling"], "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: synthetic T=%d p=%d q=%d, %d restarts/GPU, niter=%d, "
-                                   "tol=0, %s mask" % (args.workload, T, p, q, cells, niter,
-                                                       args.mask),
-                       "restarts_per_gpu": cells, "niter": niter, "algo": args.algo,
-                       "units_per_step": units_per_step, "sharding": "restarts/%d" % world},
+            "config": {"workload": "%s: synthetic T=%d p=%d q=%d, %d series x %d restarts%s, "
+                                   "niter=%d, tol=0, %s mask"
+                                   % (args.workload, T, p, q, w["series"], w["restarts"],
+                                      "/GPU" if w["scaling"] == "weak" else " in total", niter,
+                                      args.mask if w["series"] == 1 else "paleo-style"),
+                       "cells_rank0": cells, "cells_total": n_global, "niter": niter,
+                       "algo": args.algo, "units_per_step": units_per_step,
+                       "sharding": "contiguous cell ranges over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_pmc_traffic(args.workload),

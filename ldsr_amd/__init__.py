@@ -5,3 +5,4 @@ host-side mirror of the reference's operator interface (api.py)."""
 from .api import (ALGO_AUTO, ALGO_SCAN, ALGO_SERIAL, Kalman_smoother, LDS_EM,  # noqa: F401
                   LDS_EM_restart, Mstep, em_batch, make_init, pack_theta, propagate,
                   select_restart, smooth_batch, unpack_theta)
+from . import cv, shard  # noqa: F401,E402

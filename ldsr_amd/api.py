@@ -62,10 +62,14 @@ def unpack_theta(th, p, q):
             "V1": th[5 + p + q:6 + p + q].reshape(1, 1).copy()}
 
 
-def make_init(p, q, num_restarts, seed=None):
+def make_init(p, q, num_restarts, seed=None, r_seed=None):
     """List of `num_restarts` random initial thetas with the reference's distribution.
-    (R's Mersenne-Twister stream is not reproduced; pass an explicit `init` list made in R to
-    replay an R session.)"""
+    r_seed=k reproduces R's `set.seed(k); make_init(p, q, num_restarts)` draw for draw
+    (ldsr_amd/rrng.py); otherwise the counter-based generator of synth.py is used."""
+    if r_seed is not None:
+        from .rrng import make_init_packed_r
+        packed = make_init_packed_r(p, q, num_restarts, r_seed)
+        return [unpack_theta(t, p, q) for t in packed]
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1)[0])
     packed = make_init_packed(p, q, num_restarts, seed=seed)

@@ -1,0 +1,118 @@
+"""Cross-validation grid on the batched engine.
+
+The reference runs one `one_lds_cv` per fold (R/LDS_reconstruction.R:270-285, fan-out at
+:373-375): hide the fold's instrumental points (`y[instPeriod][z] <- NA`), draw fresh
+restarts, run LDS_EM_restart, return the winner's fitted Y over the instrumental period.
+Here every (fold, restart) cell goes into ONE launch (shared u, v; one NA mask of y per
+fold), the per-fold winner is picked with the reference's rule and the winners' fits come
+from one batched smoother call.
+
+Metrics follow src/utils.cpp:13-97 and calculate_metrics (R/utils.R:56-70).  Indices are
+0-based here (R's are 1-based)."""
+import numpy as np
+
+from . import api
+from .rrng import make_init_packed_r
+from .synth import make_init_packed
+
+
+def make_Z(obs, nRuns=30, frac=0.1, contiguous=True, rng=None):
+    """Cross-validation folds (R/utils.R:83-101): list of index arrays into `obs`."""
+    rng = np.random.default_rng() if rng is None else rng
+    obs = np.asarray(obs, dtype=np.float64)
+    obs_ind = np.nonzero(~np.isnan(obs))[0]
+    if frac == 1:
+        return [np.array([i]) for i in obs_ind]
+    n = obs_ind.size
+    k = int(np.floor(n * frac))
+    if contiguous:
+        max_ind = n - k
+        if max_ind < nRuns:            # not enough samples, reduce k
+            max_ind = nRuns
+            k = n - nRuns
+        starts = np.sort(rng.choice(np.arange(1, max_ind + 1), size=nRuns, replace=False))
+        return [obs_ind[x - 1:x + k] for x in starts]      # x:(x+k) has k+1 points
+    return [np.sort(rng.choice(obs_ind, size=k, replace=False)) for _ in range(nRuns)]
+
+
+# ---- skill metrics (src/utils.cpp) -------------------------------------------------------
+def NSE(yhat, y):
+    yhat, y = np.asarray(yhat, float), np.asarray(y, float)
+    return 1.0 - np.sum((y - yhat) ** 2) / np.sum((y - y.mean()) ** 2)
+
+
+def nRMSE(yhat, y, normConst):
+    yhat, y = np.asarray(yhat, float), np.asarray(y, float)
+    return np.sqrt(np.mean((y - yhat) ** 2)) / normConst
+
+
+def corr(x, y):
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    return np.sum((x - x.mean()) / x.std(ddof=1) * (y - y.mean()) / y.std(ddof=1)) / (x.size - 1)
+
+
+def KGE(yhat, y):
+    yhat, y = np.asarray(yhat, float), np.asarray(y, float)
+    r = corr(yhat, y)
+    alpha = yhat.std(ddof=1) / y.std(ddof=1)
+    beta = yhat.mean() / y.mean()
+    return 1.0 - np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2 + (beta - 1) ** 2)
+
+
+def RE(yhat, y, yc_bar):
+    yhat, y = np.asarray(yhat, float), np.asarray(y, float)
+    return 1.0 - np.sum((y - yhat) ** 2) / np.sum((y - yc_bar) ** 2)
+
+
+def calculate_metrics(sim, obs, z, norm_fun=np.nanmean):
+    """R/utils.R:56-70.  sim, obs over the instrumental period; z = held-out indices."""
+    sim, obs = np.asarray(sim, float), np.asarray(obs, float)
+    mask = np.ones(obs.size, bool)
+    mask[z] = False
+    train_obs, train_sim = obs[mask], sim[mask]
+    ok = ~np.isnan(train_obs)
+    train_obs, train_sim = train_obs[ok], train_sim[ok]
+    return {"R2": NSE(train_sim, train_obs), "RE": RE(sim[z], obs[z], train_obs.mean()),
+            "CE": NSE(sim[z], obs[z]), "nRMSE": nRMSE(sim[z], obs[z], norm_fun(obs)),
+            "KGE": KGE(sim[z], obs[z])}
+
+
+def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed=1, r_seed=None,
+            mu=0.0, device=0, engine=None):
+    """All folds x restarts in one launch.
+
+    y [T] (centred, NaN outside the instrumental period), u [p,T] / v [q,T] or None,
+    inst_period: indices of the instrumental years in y, Z: list of index arrays into the
+    instrumental period.  Returns dict(Ycv [n_folds, len(inst_period)] = winner's fitted Y
+    + mu, theta [n_folds, P], lik, winner, all=...).  `engine` may replace api.em_batch /
+    api.smooth_batch (tests use the CPU oracle to check this host logic)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    inst_period = np.asarray(inst_period)
+    p = 1 if u is None else np.asarray(u).shape[0]
+    q = 1 if v is None else np.asarray(v).shape[0]
+    F = len(Z)
+    Y = np.repeat(y[None], F, axis=0)
+    for f, z in enumerate(Z):
+        Y[f, inst_period[np.asarray(z)]] = np.nan          # y[instPeriod][z] <- NA  (:274)
+    off = (np.arange(F + 1) * num_restarts).astype(np.int32)
+    if r_seed is not None:
+        th0 = make_init_packed_r(p, q, F * num_restarts, r_seed)   # fresh make_init per fold (:275)
+    else:
+        th0 = make_init_packed(p, q, F * num_restarts, seed=seed)
+    em = engine["em_batch"] if engine else api.em_batch
+    sm = engine["smooth_batch"] if engine else api.smooth_batch
+    sel = engine["select"] if engine else api.select_restart
+    kw = {} if engine else {"device": device}
+    r = em(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol, **kw)
+    winner = np.full(F, -1, dtype=np.int64)
+    for f in range(F):
+        a, b = off[f], off[f + 1]
+        k = sel(r["lik"][a:b], r["theta"][a:b], p, q)
+        if k < 0:
+            raise RuntimeError("fold %d: no restart produced a finite likelihood" % f)
+        winner[f] = a + k
+    th_w = r["theta"][winner]
+    fit = sm(Y, u, v, th_w, cell_offsets=np.arange(F + 1, dtype=np.int32), **kw)
+    Ycv = fit["Y"][:, inst_period] + mu                      # fit$Y[instPeriod] + mu  (:283)
+    return {"Ycv": Ycv, "theta": th_w, "lik": r["lik"][winner], "winner": winner, "Z": Z,
+            "all": r}

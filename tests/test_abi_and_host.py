@@ -131,3 +131,75 @@ def test_synthetic_generator_is_shard_independent():
     y, u, v = synth.make_series(300, 1, 2, mask="paleo")
     assert np.isnan(y[:270]).all() and np.isfinite(y[270:]).all()
     assert abs(np.nanmean(y)) < 1e-12
+
+
+def test_r_compatible_uniforms_match_published_r_draws():
+    """set.seed(k); runif(3) in R (widely published first draws of the default Mersenne-Twister)."""
+    from ldsr_amd.rrng import RUniform, make_init_packed_r
+    np.testing.assert_allclose(RUniform(1).runif(3), [0.2655087, 0.3721239, 0.5728534], atol=5e-8)
+    np.testing.assert_allclose(RUniform(42).runif(3), [0.9148060, 0.9370754, 0.2861395], atol=5e-8)
+    np.testing.assert_allclose(RUniform(123).runif(3), [0.2875775, 0.7883051, 0.4089769], atol=5e-8)
+    th = make_init_packed_r(2, 1, 2, r_seed=1)
+    # draw order per restart: A, B[0..p-1] on (-1,1), C, D on (-1,1)   (R/LDS_reconstruction.R:18-21)
+    u = RUniform(1).unif_rand(10)
+    assert th[0, 0] == u[0] and th[0, 1] == -1 + 2 * u[1] and th[0, 2] == -1 + 2 * u[2]
+    assert th[0, 3] == u[3] and th[0, 4] == -1 + 2 * u[4] and th[1, 0] == u[5]
+    assert np.all(th[:, 5:] == [1, 1, 0, 1])
+
+
+def test_make_Z_and_metrics_follow_the_reference():
+    from ldsr_amd import cv
+    obs = np.arange(46, dtype=float)
+    Z = cv.make_Z(obs, nRuns=30, frac=0.25, contiguous=True, rng=np.random.default_rng(0))
+    assert len(Z) == 30 and all(len(z) == 12 for z in Z)          # k+1 = floor(46*.25)+1 points
+    assert all(np.all(np.diff(z) == 1) for z in Z) and max(z[-1] for z in Z) <= 45
+    Z1 = cv.make_Z(obs, frac=1)
+    assert len(Z1) == 46
+    rng = np.random.default_rng(1)
+    y = rng.normal(5, 1, 40)
+    yhat = y + rng.normal(0, 0.3, 40)
+    assert cv.NSE(y, y) == 1.0 and cv.RE(y, y, 0.0) == 1.0 and abs(cv.KGE(y, y) - 1.0) < 1e-12
+    assert abs(cv.corr(y, yhat) - np.corrcoef(y, yhat)[0, 1]) < 1e-12
+    m = cv.calculate_metrics(yhat, y, np.arange(10, 20))
+    assert set(m) == {"R2", "RE", "CE", "nRMSE", "KGE"} and m["CE"] <= m["RE"] + 1e-12
+
+
+def test_cv_grid_host_logic_with_oracle_engine():
+    """Fold masking, per-fold selection and winner-fit extraction of cv_grid, with the CPU
+    oracle standing in for the GPU engine (host logic only)."""
+    from ldsr_amd import cv, synth
+    from oracle import oracle as O
+
+    T, p, q = 90, 1, 2
+    y, u, v = synth.make_series(T, p, q, series_id=77, mask="paleo", n_tail=40)
+    inst = np.arange(50, 90)
+    Z = [np.arange(0, 5), np.arange(20, 26), np.arange(34, 40)]
+
+    def em_batch(Y, u_, v_, th0, cell_offsets=None, niter=1000, tol=1e-5):
+        S = Y.shape[0]
+        soc = np.repeat(np.arange(S), np.diff(cell_offsets)).astype(np.int32)
+        U = np.repeat(np.ascontiguousarray(u_.T)[None], S, axis=0)
+        V = np.repeat(np.ascontiguousarray(v_.T)[None], S, axis=0)
+        th, lik, nit, st = O.em_batch(Y, U, V, soc, th0, niter, tol, n_threads=2)
+        return {"theta": th, "lik": lik, "n_iter": nit, "status": st}
+
+    def smooth_batch(Y, u_, v_, th, cell_offsets=None):
+        fits = [O.kalman_smoother(Y[f], u_, v_, th[f]) for f in range(Y.shape[0])]
+        return {k: np.stack([f_[k] for f_ in fits]) for k in "XYVJ"}
+
+    eng = {"em_batch": em_batch, "smooth_batch": smooth_batch,
+           "select": lambda l, t, p_, q_: O.select(l, t[:, 1 + p_])}
+    r = cv.cv_grid(y, u, v, inst, Z, num_restarts=4, niter=30, tol=1e-5, seed=3, mu=2.5, engine=eng)
+    assert r["Ycv"].shape == (3, 40) and np.all(np.isfinite(r["Ycv"]))
+    # fold 1 by hand
+    y1 = y.copy()
+    y1[inst[Z[1]]] = np.nan
+    th0 = synth.make_init_packed(p, q, 12, seed=3)[4:8]
+    best, best_lik = None, -np.inf
+    for t0 in th0:
+        f = O.lds_em(y1, u, v, t0, 30, 1e-5)
+        if f["theta"][1 + p] > 0 and f["lik"] > best_lik:
+            best, best_lik = f, f["lik"]
+    np.testing.assert_allclose(r["Ycv"][1], best["fit"]["Y"][inst] + 2.5, rtol=1e-12)
+    m = cv.calculate_metrics(r["Ycv"][1], y[inst] + 2.5, Z[1])
+    assert np.isfinite(list(m.values())).all()

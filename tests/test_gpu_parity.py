@@ -264,6 +264,37 @@ def test_multi_series_own_inputs(eng, O, algo):
     _assert_batch_parity(r, ref, "multi series")
 
 
+def test_cv_grid_matches_oracle_engine(eng, O, npcase):
+    """cvLDS grid (section 8 f-2) on the bundled NP data: folds x restarts in one launch; the
+    per-fold winners and their fitted Y must match the same host logic run on the oracle."""
+    from ldsr_amd import cv
+    c = npcase(1800)
+    inst = np.nonzero(~np.isnan(c["y"]))[0]
+    Z = cv.make_Z(c["y"][inst], nRuns=6, frac=0.25, rng=np.random.default_rng(2))
+
+    def em_batch(Y, u_, v_, th0, cell_offsets=None, niter=1000, tol=1e-5):
+        soc = np.repeat(np.arange(Y.shape[0]), np.diff(cell_offsets)).astype(np.int32)
+        th, lik, nit, st = _oracle_batch(O, Y, u_, v_, th0, niter, tol, soc=soc)
+        return {"theta": th, "lik": lik, "n_iter": nit, "status": st}
+
+    def smooth_batch(Y, u_, v_, th, cell_offsets=None):
+        fits = [O.kalman_smoother(Y[f], u_, v_, th[f]) for f in range(Y.shape[0])]
+        return {k: np.stack([f_[k] for f_ in fits]) for k in "XYVJ"}
+
+    ref_eng = {"em_batch": em_batch, "smooth_batch": smooth_batch,
+               "select": lambda l, t, p_, q_: O.select(l, t[:, 1 + p_])}
+    kw = dict(num_restarts=8, niter=300, tol=1e-5, r_seed=7, mu=c["mu"])
+    g = cv.cv_grid(c["y"], c["u"], c["v"], inst, Z, **kw)
+    r = cv.cv_grid(c["y"], c["u"], c["v"], inst, Z, engine=ref_eng, **kw)
+    assert np.array_equal(g["winner"], r["winner"])
+    assert np.array_equal(g["all"]["n_iter"], r["all"]["n_iter"])
+    assert parity_close(g["Ycv"], r["Ycv"], RTOL, ATOL)
+    for f, z in enumerate(Z):
+        mg = cv.calculate_metrics(g["Ycv"][f], c["y"][inst] + c["mu"], z)
+        mr = cv.calculate_metrics(r["Ycv"][f], c["y"][inst] + c["mu"], z)
+        assert parity_close(list(mg.values()), list(mr.values()), 1e-5, 1e-8)
+
+
 def test_restart_selection_and_winner_fit(eng, O, p1case):
     c = p1case
     init = eng.make_init(7, 7, 24, seed=1)
