@@ -128,6 +128,36 @@ __device__ __forceinline__ void prenorm(PMat &m) {
     m.m22 = __builtin_amdgcn_ldexp(m.m22, e);
 }
 
+// Cross-lane move of a double by DPP (no LDS round-trip).  Lanes whose DPP source does not
+// exist (outside the 16-lane row, or a row excluded by RM) receive `old`; passing the identity
+// element there makes the scan steps unconditional (verified on gfx950 by tools/dpp_probe.hip).
+template <int CTRL, int RM>
+__device__ __forceinline__ double dppd(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_ROW_SHL(n) (0x100 + (n))
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+// partner matrix of a scan round; identity where the partner lane does not exist
+template <int CTRL, int RM>
+__device__ __forceinline__ PMat pdpp(const PMat &m) {
+    PMat r;
+    r.m00 = dppd<CTRL, RM>(1.0, m.m00);
+    r.m01 = dppd<CTRL, RM>(0.0, m.m01);
+    r.m10 = dppd<CTRL, RM>(0.0, m.m10);
+    r.m11 = dppd<CTRL, RM>(1.0, m.m11);
+    r.m20 = dppd<CTRL, RM>(0.0, m.m20);
+    r.m21 = dppd<CTRL, RM>(0.0, m.m21);
+    r.m22 = dppd<CTRL, RM>(1.0, m.m22);
+    return r;
+}
+
 __device__ __forceinline__ PMat pshfl_up(const PMat &m, int d) {
     PMat r;
     r.m00 = __shfl_up(m.m00, d, 64);
@@ -278,36 +308,38 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         }
 
         // ------------------------------------------------ forward scan (inclusive, by lane)
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const PMat Pm = pshfl_up(M, d);
-            if (lane >= d) M = pmul(M, Pm);
-            if (d == 4) prenorm(M);
-        }
-        // M now composes lanes max(0, l-31) .. l.  State after this lane's chunk: lanes < 32
-        // apply M to the initial state; lanes >= 32 apply it to the state of lane l-32 (a
-        // matrix-vector product instead of a sixth matrix-matrix round).
+        // rows of 16 lanes: Kogge-Stone by DPP row shifts (identity outside the row) ...
+        M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
+        M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
+        M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
+        prenorm(M);
+        M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
+        // ... then row totals: lane 15 -> row 1, lane 47 -> row 3
+        M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));
+        // M composes lanes 0..l (rows 0,1) or 32..l (rows 2,3).  State after this lane's chunk:
+        // rows 0,1 apply M to the initial state, rows 2,3 to the state of lane 31 (a matrix-vector
+        // product instead of a sixth matrix-matrix round).
         double n_e = fma(M.m00, th.V1, M.m01);
         double d_e = fma(M.m10, th.V1, M.m11);
         double x_e = fma(M.m20, th.V1, fma(M.m22, th.mu1, M.m21));
         {
-            const double n_b = __shfl_up(n_e, 32, 64), d_b = __shfl_up(d_e, 32, 64),
-                         x_b = __shfl_up(x_e, 32, 64);
-            if (lane >= 32) {
-                n_e = fma(M.m00, n_b, M.m01 * d_b);
-                d_e = fma(M.m10, n_b, M.m11 * d_b);
-                x_e = fma(M.m20, n_b, fma(M.m21, d_b, M.m22 * x_b));
-            }
+            const double n_b = dppd<DPP_ROW_BCAST31, 0xC>(th.V1, n_e);
+            const double d_b = dppd<DPP_ROW_BCAST31, 0xC>(1.0, d_e);
+            const double x_b = dppd<DPP_ROW_BCAST31, 0xC>(th.mu1, x_e);
+            n_e = fma(M.m00, n_b, M.m01 * d_b);
+            d_e = fma(M.m10, n_b, M.m11 * d_b);
+            x_e = fma(M.m20, n_b, fma(M.m21, d_b, M.m22 * x_b));
         }
-        // shift by one lane: the entry state of lane l is the exit state of lane l-1
-        n_e = __shfl_up(n_e, 1, 64);
-        d_e = __shfl_up(d_e, 1, 64);
-        x_e = __shfl_up(x_e, 1, 64);
+        // shift by one lane: the entry state of lane l is the exit state of lane l-1; lane 0
+        // gets the initial state (V1, 1, mu1)
+        n_e = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, n_e);
+        d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
+        x_e = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, x_e);
         double Xp, Vp;
         {
             const double rd = fast_rcp(d_e);
-            Vp = (lane == 0) ? th.V1 : n_e * rd;
-            Xp = (lane == 0) ? th.mu1 : x_e * rd;
+            Vp = n_e * rd;
+            Xp = x_e * rd;
         }
 
         // ------------------------------------------------ F2: serial re-run from the exact entry
@@ -390,23 +422,38 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
             for (int j = L - 2; j >= 0; j--) b1(j);
         }
-        // reverse inclusive scan: lane l composes its map after those of lanes > l
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double Pb = __shfl_down(Pi, d, 64);
-            const double Gb = __shfl_down(G, d, 64);
-            const double Hb = __shfl_down(H, d, 64);
-            if (lane + d < 64) {
-                G = fma(Pi, Gb, G);
-                H = fma(Pi * Pi, Hb, H);
-                Pi *= Pb;
-            }
+        // reverse inclusive scan: lane l composes its map after those of lanes > l.
+        // Within rows by DPP row shifts (identity outside the row) ...
+#define RSCAN_ROUND(n)                                                     \
+        {                                                                  \
+            const double Pb = dppd<DPP_ROW_SHL(n), 0xF>(1.0, Pi);          \
+            const double Gb = dppd<DPP_ROW_SHL(n), 0xF>(0.0, G);           \
+            const double Hb = dppd<DPP_ROW_SHL(n), 0xF>(0.0, H);           \
+            G = fma(Pi, Gb, G);                                            \
+            H = fma(Pi * Pi, Hb, H);                                       \
+            Pi *= Pb;                                                      \
+        }
+        RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+        // ... then across rows: lanes 16, 32, 48 hold the composites T1, T2, T3 of rows 1..3;
+        // every lane applies the composite of all rows after its own (uniform values)
+        {
+            const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
+            const double P2 = readlane_d(Pi, 32), G2 = readlane_d(G, 32), H2 = readlane_d(H, 32);
+            const double P1 = readlane_d(Pi, 16), G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
+            const double G23 = fma(P2, G3, G2), H23 = fma(P2 * P2, H3, H2);   // T2 o T3
+            const double G123 = fma(P1, G23, G1), H123 = fma(P1 * P1, H23, H1);              // T1 o T2 o T3
+            const int row = lane >> 4;
+            const double Gs = row == 0 ? G123 : row == 1 ? G23 : row == 2 ? G3 : 0.0;
+            const double Hs = row == 0 ? H123 : row == 1 ? H23 : row == 2 ? H3 : 0.0;
+            G = fma(Pi, Gs, G);
+            H = fma(Pi * Pi, Hs, H);
         }
         // (G, H) = (Xs, Vs) at the first step of this lane's chunk (terminal value is zero);
-        // the entry for lane l is lane l+1's value
-        double Xn = __shfl_down(G, 1, 64);
-        double Vn = __shfl_down(H, 1, 64);
-        if (lane >= lastLane) { Xn = 0.0; Vn = 0.0; }
+        // the entry for lane l is lane l+1's value, zero beyond the last active lane (inactive
+        // lanes hold identity maps, so their G = H = 0)
+        double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+        double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
 
         // ------------------------------------------------ B2: serial reverse re-run + M-step sums
         double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, term = 0.0;
@@ -415,17 +462,34 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < QQ; k++) aSxv[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < PP; k++) { aTx1u[k] = 0.0; aTux[k] = 0.0; }
-        double Xs = 0.0, Vs = 0.0;
-        auto b2 = [&](int j) {
-            const bool o = DENSE || ((obsmask >> j) & 1u);
+        // pass 1 (registers only): the serial recurrence; Xs_t, Vs_t overwrite g_t, h_t
+        const double XnE = Xn, VnE = Vn;       // Xs, Vs just after this lane's chunk
+        auto b2a = [&](int j) {
             const double J = Jv[j];
-            Xs = fma(J, Xn, gv_[j]);        // :101
-            Vs = fma(J * J, Vn, hv[j]);     // :102
-            aTx1x = fma(Xn, Xs, fma(Vn, J, aTx1x));   // :180  (zero at t = T-1)
+            const double Xs = fma(J, Xn, gv_[j]);        // :101
+            const double Vs = fma(J * J, Vn, hv[j]);     // :102
+            gv_[j] = Xs;
+            hv[j] = Vs;
+            Xn = Xs;
+            Vn = Vs;
+        };
+        if (act) {
+            if (tail) b2a(L - 1);
+            else { gv_[L - 1] = XnE; hv[L - 1] = VnE; }  // "next" of step L-2 for short chunks
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2a(j);
+        }
+        // pass 2: every M-step sum; no dependence between steps, LDS reads batch freely
+        auto b2b = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            const double J = Jv[j], Xs = gv_[j], Vs = hv[j];
+            const double Xnx = (j == L - 1) ? XnE : gv_[j + 1 < L ? j + 1 : j];
+            const double Vnx = (j == L - 1) ? VnE : hv[j + 1 < L ? j + 1 : j];
+            aTx1x = fma(Xnx, Xs, fma(Vnx, J, aTx1x));   // :180  (zero at t = T-1)
 #pragma unroll
             for (int k = 0; k < PP; k++) {
                 const double ut = us[(j * PP + k) * 64 + lane];   // zero at t = T-1
-                aTx1u[k] = fma(Xn, ut, aTx1u[k]);                 // :190
+                aTx1u[k] = fma(Xnx, ut, aTx1u[k]);                // :190
                 aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
             }
             term = fma(Xs, Xs, Vs);
@@ -435,14 +499,13 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             if (!DENSE) aSxx += o ? term : 0.0;                   // :152
 #pragma unroll
             for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
-            Xn = Xs;
-            Vn = Vs;
         };
         if (act) {
-            if (tail) b2(L - 1);
+            if (tail) b2b(L - 1);
 #pragma unroll
-            for (int j = L - 2; j >= 0; j--) b2(j);
+            for (int j = L - 2; j >= 0; j--) b2b(j);
         }
+        const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
         Sums<PP, QQ> S;
         {
             constexpr int NR = 3 + (DENSE ? 0 : 1) + QQ + 2 * PP;
