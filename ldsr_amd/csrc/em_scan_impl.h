@@ -394,20 +394,10 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         }
         const double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);   // Xs^2 + Vs at T-1
 
-        // likelihood (:113-124)
-        {
-            double l2[2] = {likq, log(sprod)};
-            wave_sum_n<2>(l2);
-            lik2 = lik1;
-            lik1 = lik;
-            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (l2[0] + l2[1])) / n_obs;
-            if (__any(sneg < 0)) lik = NAN;   // log of a negative Sigma in the reference
-        }
-        if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
-        it++;
-        bool stop = it >= prm.niter;
-        if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
-        if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
+        // The two likelihood sums ride along with the M-step sums in ONE wave reduction at the end
+        // of the iteration; the backward sweep of the final iteration is therefore redundant
+        // (1 of n_iter sweeps) but every iteration saves 6 dependent cross-lane rounds.
+        const double lsp = log(sprod);
 
         // ------------------------------------------------ B1: compose the reverse affine maps
         double Pi = 1.0, G = 0.0, H = 0.0;
@@ -508,25 +498,35 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
         Sums<PP, QQ> S;
         {
-            constexpr int NR = 3 + (DENSE ? 0 : 1) + QQ + 2 * PP;
+            constexpr int NR = 5 + (DENSE ? 0 : 1) + QQ + 2 * PP;
             double red[NR];
-            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall;
-            if (!DENSE) red[3] = aSxx;
-            constexpr int o0 = 3 + (DENSE ? 0 : 1);
+            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
+            if (!DENSE) red[5] = aSxx;
+            constexpr int o0 = 5 + (DENSE ? 0 : 1);
 #pragma unroll
             for (int k = 0; k < QQ; k++) red[o0 + k] = aSxv[k];
 #pragma unroll
             for (int k = 0; k < PP; k++) { red[o0 + QQ + k] = aTx1u[k]; red[o0 + QQ + PP + k] = aTux[k]; }
             wave_sum_n<NR>(red);
             S.Syx = red[0]; S.Tx1x = red[1];
-            S.Sxx = DENSE ? red[2] : red[3];
+            S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
             for (int k = 0; k < QQ; k++) S.Sxv[k] = red[o0 + k];
 #pragma unroll
             for (int k = 0; k < PP; k++) { S.Tx1u[k] = red[o0 + QQ + k]; S.Tux[k] = red[o0 + QQ + PP + k]; }
             S.Txx = red[2] - termLast;                  // t = 0 .. T-2
             S.Tx1x1 = red[2] - readlane_d(term, 0);     // t = 1 .. T-1
+            // likelihood (:113-124)
+            lik2 = lik1;
+            lik1 = lik;
+            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;
+            if (__any(sneg < 0)) lik = NAN;   // log of a negative Sigma in the reference
         }
+        if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
+        it++;
+        bool stop = it >= prm.niter;
+        if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
+        if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
         S.X0 = readlane_d(Xs, 0);                       // :218
         S.V0 = readlane_d(Vs, 0);                       // :219
         mstep_update(th, S, sc, T);
