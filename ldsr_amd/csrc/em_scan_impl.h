@@ -31,16 +31,6 @@
 #pragma once
 #include "ldsr_device.h"
 
-// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (the divide expansion minus its final
-// correction; parity bar is 1e-6 relative).
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
-}
-
 __device__ __forceinline__ double readlane_d(double x, int lane) {
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -276,7 +266,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     for (;;) {
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
         const double A2 = A * A, C2 = C * C;
-        const double rR = 1.0 / R;
+        const double rR = fast_rcp(R);
         const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
 
         // ------------------------------------------------ F1: compose this lane's step matrices
@@ -529,7 +519,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
         S.X0 = readlane_d(Xs, 0);                       // :218
         S.V0 = readlane_d(Vs, 0);                       // :219
-        mstep_update(th, S, sc, T);
+        mstep_update<PP, QQ, true>(th, S, sc, T);
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
         th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);

@@ -14,10 +14,11 @@
 // series_prep_kernel: one block per series.  Builds the zero-padded time-major copies of
 // u and v, and the theta-independent statistics (SeriesConst).
 // ---------------------------------------------------------------------------------------
-__device__ static bool invert_small(double *a, int n) {
+__device__ static bool invert_small(double *a, double *inv, int n) {
     // Gauss-Jordan with partial pivoting on an n x n matrix stored with stride LDSR_MAXPQ;
-    // entries outside n x n are left untouched (identity padding).  One thread.
-    double inv[LDSR_MAXPQ * LDSR_MAXPQ];
+    // entries outside n x n are left untouched (identity padding).  One thread; `a` and the
+    // workspace `inv` live in LDS (a private array would sit in scratch memory and make every
+    // access a global-memory round trip).
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) inv[i * LDSR_MAXPQ + j] = (i == j) ? 1.0 : 0.0;
     for (int c = 0; c < n; c++) {
@@ -56,11 +57,19 @@ __device__ static bool invert_small(double *a, int n) {
     return true;
 }
 
-#define PREP_TILE 256
+__device__ __forceinline__ double prep_wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// One workgroup (4 waves) per series.  Every theta-independent statistic is a wave-parallel
+// strided sum over t followed by a shuffle reduction (fixed summation tree: deterministic);
+// statistics are dealt round-robin to the 4 waves.
 __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     const int s = blockIdx.x;
     const int T = prm.T, p = prm.p, q = prm.q, PP = prm.PP, QQ = prm.QQ;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *y = prm.y + (long)s * T;
     const bool own_uv = (!prm.shared_uv) || s == 0;
     const double *u = prm.u ? prm.u + (prm.shared_uv ? 0 : (long)s * T * p) : nullptr;
@@ -69,93 +78,97 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     double *up = prm.up + (prm.shared_uv ? 0 : (long)s * T * PP);
     double *vp = prm.vp + (prm.shared_uv ? 0 : (long)s * T * QQ);
 
-    // The series is streamed through LDS in tiles of PREP_TILE steps (coalesced loads); each of
-    // the 138 statistics is owned by one thread and summed in ascending t like the reference.
-    __shared__ double ty[PREP_TILE], tu[PREP_TILE * LDSR_MAXPQ], tv[PREP_TILE * LDSR_MAXPQ];
     __shared__ SeriesConst sc;
-    // role of this thread
-    const int role = tid < 64 ? 0 : tid < 128 ? 1 : tid < 136 ? 2 : tid == 136 ? 3 : 4;
-    const int k = (role == 2) ? tid - 128 : ((tid & 63) >> 3), l = tid & 7;
-    double acc = 0.0;
-    int n = 0, first = -1, last = -1;
-    const bool live = (role == 0 && v && k < q && l < q) || (role == 1 && u && k < p && l < p) ||
-                      (role == 2 && v && k < q) || role == 3;
-    for (int tb = 0; tb < T; tb += PREP_TILE) {
-        const int nt = min(PREP_TILE, T - tb);
-        for (int i = tid; i < nt; i += 256) {
-            const double yv = y[tb + i];
-            ty[i] = yv;
-            yp[tb + i] = yv;
+    __shared__ double inv_ws[LDSR_MAXPQ * LDSR_MAXPQ];
+
+    // prepared copies
+    for (int t = tid; t < T; t += 256) yp[t] = y[t];
+    if (own_uv) {
+        for (int i = tid; i < T * PP; i += 256) {
+            const int t = i / PP, k = i - t * PP;
+            // u[:,T-1] is never read by the reference (src/EM.cpp:74,190-193): zero it
+            up[i] = (u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
         }
-        if (u)
-            for (int i = tid; i < nt * p; i += 256) tu[i] = u[(long)tb * p + i];
-        if (v)
-            for (int i = tid; i < nt * q; i += 256) tv[i] = v[(long)tb * q + i];
-        __syncthreads();
-        if (own_uv) {
-            for (int i = tid; i < nt * PP; i += 256) {
-                const int tt = i / PP, kk = i - tt * PP;
-                // u[:,T-1] is never read by the reference (src/EM.cpp:74,190-193): zero it
-                up[(long)tb * PP + i] = (u && kk < p && tb + tt < T - 1) ? tu[tt * p + kk] : 0.0;
-            }
-            for (int i = tid; i < nt * QQ; i += 256) {
-                const int tt = i / QQ, kk = i - tt * QQ;
-                vp[(long)tb * QQ + i] = (v && kk < q) ? tv[tt * q + kk] : 0.0;
-            }
+        for (int i = tid; i < T * QQ; i += 256) {
+            const int t = i / QQ, k = i - t * QQ;
+            vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
         }
-        if (live) {
-            // branch-free bodies so the LDS reads of successive steps pipeline
-            if (role == 0) {
-#pragma unroll 8
-                for (int tt = 0; tt < nt; tt++) {
-                    const double pr = tv[tt * q + k] * tv[tt * q + l];
-                    acc += isfinite(ty[tt]) ? pr : 0.0;
-                }
-            } else if (role == 1) {
-                const int ne = min(nt, T - 1 - tb);
-#pragma unroll 8
-                for (int tt = 0; tt < ne; tt++) acc += tu[tt * p + k] * tu[tt * p + l];
-            } else if (role == 2) {
-#pragma unroll 8
-                for (int tt = 0; tt < nt; tt++) {
-                    const double yv = ty[tt];
-                    acc += isfinite(yv) ? yv * tv[tt * q + k] : 0.0;
-                }
-            } else {
-#pragma unroll 8
-                for (int tt = 0; tt < nt; tt++) {
-                    const double yv = ty[tt];
-                    const bool o = isfinite(yv);
-                    acc += o ? yv * yv : 0.0;
-                    n += o ? 1 : 0;
-                    first = (o && first < 0) ? tb + tt : first;
-                    last = o ? tb + tt : last;
-                }
-            }
-        }
-        __syncthreads();
     }
-    if (role == 0) sc.Svv_inv[k * LDSR_MAXPQ + l] = live ? acc : (k == l ? 1.0 : 0.0);
-    if (role == 1) sc.Tuu_inv[k * LDSR_MAXPQ + l] = live ? acc : (k == l ? 1.0 : 0.0);
-    if (role == 2) sc.Syv[k] = live ? acc : 0.0;
-    if (role == 3) {
-        sc.Syy = acc;
-        sc.n_obs = n;
-        sc.t_first_obs = first;
-        sc.t_last_obs = last;
+    // identity / zero padding of the statistics
+    for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
+        const double id = ((i >> 3) == (i & 7)) ? 1.0 : 0.0;
+        sc.Svv_inv[i] = id;
+        sc.Tuu_inv[i] = id;
+    }
+    if (tid < LDSR_MAXPQ) { sc.Syv[tid] = 0.0; sc.wv[tid] = 0.0; }
+    __syncthreads();
+
+    // statistic ids: [0, q*q) Svv(k,l); [.., +p*p) Tuu(k,l); [.., +q) Syv(k); last: Syy + counts
+    const int nqq = v ? q * q : 0, npp = u ? p * p : 0, nq = v ? q : 0;
+    const int n_stat = nqq + npp + nq + 1;
+    for (int id = wave; id < n_stat; id += 4) {
+        double acc = 0.0;
+        if (id < nqq) {
+            const int k = id / q, l = id - k * q;
+            for (int t = lane; t < T; t += 64)
+                acc += isfinite(y[t]) ? v[(long)t * q + k] * v[(long)t * q + l] : 0.0;   // :161
+            acc = prep_wave_sum(acc);
+            if (lane == 0) sc.Svv_inv[k * LDSR_MAXPQ + l] = acc;
+        } else if (id < nqq + npp) {
+            const int j = id - nqq, k = j / p, l = j - k * p;
+            for (int t = lane; t < T - 1; t += 64) acc += u[(long)t * p + k] * u[(long)t * p + l];   // :193
+            acc = prep_wave_sum(acc);
+            if (lane == 0) sc.Tuu_inv[k * LDSR_MAXPQ + l] = acc;
+        } else if (id < nqq + npp + nq) {
+            const int k = id - nqq - npp;
+            for (int t = lane; t < T; t += 64) {
+                const double yv = y[t];
+                acc += isfinite(yv) ? yv * v[(long)t * q + k] : 0.0;   // :158
+            }
+            acc = prep_wave_sum(acc);
+            if (lane == 0) sc.Syv[k] = acc;
+        } else {
+            int n = 0, first = T, last = -1;
+            for (int t = lane; t < T; t += 64) {
+                const double yv = y[t];
+                const bool o = isfinite(yv);
+                acc += o ? yv * yv : 0.0;
+                n += o ? 1 : 0;
+                first = (o && t < first) ? t : first;
+                last = o ? t : last;
+            }
+            acc = prep_wave_sum(acc);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                n += __shfl_xor(n, d, 64);
+                first = min(first, __shfl_xor(first, d, 64));
+                last = max(last, __shfl_xor(last, d, 64));
+            }
+            if (lane == 0) {
+                sc.Syy = acc;
+                sc.n_obs = n;
+                sc.t_first_obs = n ? first : -1;
+                sc.t_last_obs = last;
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
         bool ok = sc.n_obs > 0;
-        if (v) ok = invert_small(sc.Svv_inv, q) && ok;
-        if (u) ok = invert_small(sc.Tuu_inv, p) && ok;
+        if (v) ok = invert_small(sc.Svv_inv, inv_ws, q) && ok;
+        if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p) && ok;
         sc.status = ok ? 0 : 2;
         for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
             double a = 0.0;
             for (int ll = 0; ll < LDSR_MAXPQ; ll++) a += sc.Svv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];
             sc.wv[kk] = a;
         }
-        prm.sc[s] = sc;
+    }
+    __syncthreads();
+    {   // cooperative copy of the result to global memory
+        const int *src = reinterpret_cast<const int *>(&sc);
+        int *dst = reinterpret_cast<int *>(prm.sc + s);
+        for (int i = tid; i < (int)(sizeof(SeriesConst) / sizeof(int)); i += 256) dst[i] = src[i];
     }
 }
 
