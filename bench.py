@@ -117,15 +117,16 @@ def host_cores():
     return n
 
 
-def cpu_baseline(T, p, q, niter, y, u, v, seed):
+def cpu_baseline(p, q, niter, Y, U, V, seed):
+    """The CPU oracle on the first series of the workload (Y [S,T], U [.,T,p], V [.,T,q])."""
     from oracle import oracle as O
     cores = host_cores()
     from ldsr_amd import synth
     cells = 512 * cores
     th0 = synth.make_init_packed(p, q, cells, seed=seed)
-    Y = y[None]
-    U = np.ascontiguousarray(u.T[None])
-    V = np.ascontiguousarray(v.T[None])
+    Y = np.ascontiguousarray(Y[:1])
+    U = np.ascontiguousarray(U[:1])
+    V = np.ascontiguousarray(V[:1])
     soc = np.zeros(cells, np.int32)
     O.em_batch(Y, U, V, soc[:cores], th0[:cores], 3, 0.0, n_threads=cores)      # warm
     t0 = time.perf_counter()
@@ -259,7 +260,7 @@ def main():
                                  "HBM traffic is far below it"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, p, q, niter, y, u, v, seed=1)
+            out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
