@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libldsr_hip.so")
+# LDSR_HIP_SO overrides the library path (A/B runs of two builds on the same GPU box)
+SO_PATH = os.environ.get("LDSR_HIP_SO") or os.path.join(_HERE, "libldsr_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

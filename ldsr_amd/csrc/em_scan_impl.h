@@ -174,7 +174,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                                              int lane, int nl, int rp);
 
 template <int PP, int QQ, int L>
-__global__ __launch_bounds__((L > 16) ? 256 : 512) void em_scan_kernel(EmParams prm) {
+__global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
     // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
     double *ys = smem;                  // [L][64]       y, 0 where missing / unused
@@ -261,7 +261,14 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
-    double Jv[L], gv_[L], hv[L];
+    // Per-step (J_t, g_t, h_t) kept in registers between the forward and the backward sweep.
+    // Chunks longer than 16 steps (T > 1024) would need more than 256 VGPRs and drop to one
+    // wave per SIMD, so for them only the second half [HS, L) is kept; the reverse composite is
+    // accumulated during the forward sweep and the first half's forward recursion is re-run
+    // just before its backward sweep (+~20 % flops, twice the occupancy).
+    constexpr int HS = (L > 16) ? L / 2 : 0;
+    constexpr int NS = L - HS;
+    double Jv[NS], gv_[NS], hv[NS];
 
     for (;;) {
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
@@ -291,8 +298,14 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
         };
         if (act) {
+            if (L <= 16) {
 #pragma unroll
-            for (int j = 0; j < L - 1; j++) f1(j);
+                for (int j = 0; j < L - 1; j++) f1(j);
+            } else {           // no register arrays here: keep long chunks rolled (code size, VGPRs)
+                f1(0);
+#pragma unroll 4
+                for (int j = 1; j < L - 1; j++) f1(j);
+            }
             if (tail) f1(L - 1);
             prenorm(M);
         }
@@ -337,6 +350,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         int sneg = 0;   // OR of the sign words of every observed Sigma_t
         double sg = fma(C2, Vp, R);     // Sigma_t of the current step (src/EM.cpp:119)
         double r0 = fast_rcp(sg);
+        const double Xp0 = Xp, Vp0 = Vp, sg0 = sg, r00 = r0;   // entry state (re-run of [0, HS))
+        double Pi = 1.0, G = 0.0, H = 0.0;                     // reverse composite (HS > 0 only)
         auto f2 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
             double e = ys[j * 64 + lane];
@@ -363,24 +378,32 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             const double rp1 = sg * z;
             r0 = Vp1 * z;
             const double AVu = A * Vu;
-            const double J = AVu * rp1;                // :100
-            Jv[j] = J;
-            gv_[j] = fma(-J, Xp1, Xu);
-            hv[j] = fma(-J, AVu, Vu);
+            double J = AVu * rp1;                      // :100
+            double g = fma(-J, Xp1, Xu);
+            double h = fma(-J, AVu, Vu);
+            if (j >= L - 2) {
+                // Step T-1 starts the backward recursion: Xs_{T-1} = Xu_{T-1}, Vs_{T-1} = Vu_{T-1}
+                // (:94-95).  Expressed as J = 0, g = Xu, h = Vu with a zero terminal value,
+                // which also makes the (T-1, T) term of every pair sum vanish.
+                const bool fin = (lane == lastLane) && (j == (tail ? L - 1 : L - 2));
+                J = fin ? 0.0 : J;
+                g = fin ? Xu : g;
+                h = fin ? Vu : h;
+            }
+            if (j >= HS) { Jv[j - HS] = J; gv_[j - HS] = g; hv[j - HS] = h; }
+            if (HS > 0) {      // steps arrive in time order: (Pi,G,H) o step_j
+                G = fma(Pi, g, G);
+                H = fma(Pi * Pi, h, H);
+                Pi *= J;
+            }
             Xp = Xp1;
             Vp = Vp1;
+            if (L > 16) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
 #pragma unroll
             for (int j = 0; j < L - 1; j++) f2(j);
             if (tail) f2(L - 1);
-        }
-        // Step T-1 starts the backward recursion: Xs_{T-1} = Xu_{T-1}, Vs_{T-1} = Vu_{T-1}
-        // (:94-95).  Expressed as J = 0, g = Xu, h = Vu with a zero terminal value, which also
-        // makes the (T-1, T) term of every pair sum vanish.
-        if (lane == lastLane) {
-            if (tail) { Jv[L - 1] = 0.0; gv_[L - 1] = Xu; hv[L - 1] = Vu; }
-            else      { Jv[L - 2] = 0.0; gv_[L - 2] = Xu; hv[L - 2] = Vu; }
         }
         const double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);   // Xs^2 + Vs at T-1
 
@@ -390,14 +413,13 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         const double lsp = log(sprod);
 
         // ------------------------------------------------ B1: compose the reverse affine maps
-        double Pi = 1.0, G = 0.0, H = 0.0;
         auto b1 = [&](int j) {
             const double J = Jv[j];
             G = fma(J, G, gv_[j]);
             H = fma(J * J, H, hv[j]);
             Pi *= J;
         };
-        if (act) {
+        if (HS == 0 && act) {
             if (tail) b1(L - 1);
 #pragma unroll
             for (int j = L - 2; j >= 0; j--) b1(j);
@@ -442,29 +464,25 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < QQ; k++) aSxv[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < PP; k++) { aTx1u[k] = 0.0; aTux[k] = 0.0; }
-        // pass 1 (registers only): the serial recurrence; Xs_t, Vs_t overwrite g_t, h_t
-        const double XnE = Xn, VnE = Vn;       // Xs, Vs just after this lane's chunk
-        auto b2a = [&](int j) {
-            const double J = Jv[j];
-            const double Xs = fma(J, Xn, gv_[j]);        // :101
-            const double Vs = fma(J * J, Vn, hv[j]);     // :102
-            gv_[j] = Xs;
-            hv[j] = Vs;
+        // One segment = the stored steps [HS, L) (all steps when HS == 0), then for HS > 0 the
+        // re-run steps [0, HS).  pass 1 (registers only): the serial recurrence, Xs_t / Vs_t
+        // overwrite g_t / h_t;  pass 2: every M-step sum, no dependence between steps so the
+        // LDS reads batch freely.
+        double XnE = Xn, VnE = Vn;             // Xs, Vs just after the current segment
+        auto b2a = [&](int i) {                // i = index into the stored arrays
+            const double J = Jv[i];
+            const double Xs = fma(J, Xn, gv_[i]);        // :101
+            const double Vs = fma(J * J, Vn, hv[i]);     // :102
+            gv_[i] = Xs;
+            hv[i] = Vs;
             Xn = Xs;
             Vn = Vs;
         };
-        if (act) {
-            if (tail) b2a(L - 1);
-            else { gv_[L - 1] = XnE; hv[L - 1] = VnE; }  // "next" of step L-2 for short chunks
-#pragma unroll
-            for (int j = L - 2; j >= 0; j--) b2a(j);
-        }
-        // pass 2: every M-step sum; no dependence between steps, LDS reads batch freely
-        auto b2b = [&](int j) {
+        auto b2b = [&](int j, int i, bool top) {   // j = step in the chunk, i = storage index
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double J = Jv[j], Xs = gv_[j], Vs = hv[j];
-            const double Xnx = (j == L - 1) ? XnE : gv_[j + 1 < L ? j + 1 : j];
-            const double Vnx = (j == L - 1) ? VnE : hv[j + 1 < L ? j + 1 : j];
+            const double J = Jv[i], Xs = gv_[i], Vs = hv[i];
+            const double Xnx = top ? XnE : gv_[top ? i : i + 1];
+            const double Vnx = top ? VnE : hv[top ? i : i + 1];
             aTx1x = fma(Xnx, Xs, fma(Vnx, J, aTx1x));   // :180  (zero at t = T-1)
 #pragma unroll
             for (int k = 0; k < PP; k++) {
@@ -479,11 +497,63 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             if (!DENSE) aSxx += o ? term : 0.0;                   // :152
 #pragma unroll
             for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
+            if (L > 16 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
-            if (tail) b2b(L - 1);
+            if (tail) b2a(NS - 1);
+            else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }  // "next" of step L-2 for short chunks
 #pragma unroll
-            for (int j = L - 2; j >= 0; j--) b2b(j);
+            for (int i = NS - 2; i >= 0; i--) b2a(i);
+            if (tail) b2b(L - 1, NS - 1, true);
+#pragma unroll
+            for (int i = NS - 2; i >= 0; i--) b2b(HS + i, i, false);
+        }
+        if (HS > 0) {
+            // re-run the forward recursion of steps [0, HS) from the lane's entry state; the
+            // likelihood terms of these steps were already accumulated in F2
+            double Xq = Xp0, Vq = Vp0, sgq = sg0, rq = r00;
+            auto f2r = [&](int j) {
+                const bool o = DENSE || ((obsmask >> j) & 1u);
+                double e = ys[j * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+                double bu = 0.0;
+#pragma unroll
+                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+                const double r = o ? rq : 0.0;
+                const double w = Vq * r;
+                const double K = C * w;
+                double Vuq;
+                if (DENSE) Vuq = R * w;
+                else Vuq = fma(-(C2 * w), Vq, Vq);
+                const double dl = fma(-C, Xq, e);
+                const double Xuq = fma(K, dl, Xq);
+                const double Vp1 = fma(A2, Vuq, Q);
+                const double Xp1 = fma(A, Xuq, bu);
+                sgq = fma(C2, Vp1, R);
+                const double z = fast_rcp(sgq * Vp1);
+                const double rp1 = sgq * z;
+                rq = Vp1 * z;
+                const double AVu = A * Vuq;
+                const double J = AVu * rp1;
+                Jv[j] = J;
+                gv_[j] = fma(-J, Xp1, Xuq);
+                hv[j] = fma(-J, AVu, Vuq);
+                Xq = Xp1;
+                Vq = Vp1;
+                __builtin_amdgcn_sched_barrier(0);   // keep later steps' LDS loads from being hoisted (VGPR pressure)
+            };
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < HS; j++) f2r(j);
+                XnE = Xn;                      // Xs, Vs at step HS: the entry of this segment
+                VnE = Vn;
+#pragma unroll
+                for (int i = HS - 1; i >= 0; i--) b2a(i);
+                b2b(HS - 1, HS - 1, true);
+#pragma unroll
+                for (int i = HS - 2; i >= 0; i--) b2b(i, i, false);
+            }
         }
         const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
         Sums<PP, QQ> S;
@@ -543,11 +613,11 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 static inline int scan_wpb(int L, int PP, int QQ) {
     const size_t lds = (size_t)64 * L * (1 + PP + QQ) * sizeof(double);
     const int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int want = (L > 16) ? 4 : 8;       // L > 16 kernels hold one wave per SIMD
+    const int want = 8;
     int wpb = (want + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
     if (wpb < 2) wpb = 2;
     if (L <= 16 && wpb < 4 && lds > 20 * 1024) wpb = 4;
-    const int cap = (L > 16) ? 4 : 8;
+    const int cap = 8;
     return wpb > cap ? cap : wpb;
 }
 
