@@ -213,6 +213,53 @@ def test_tiny_series_fixed_iterations(eng, O, algo, T, p, q):
     _assert_batch_parity(r, ref, "tiny T=%d" % T)
 
 
+@pytest.mark.parametrize("T", [128, 129, 192, 193, 256, 384, 385, 512, 513, 768, 769, 1024, 1536, 1537, 2048])
+def test_scan_chunk_length_boundaries(eng, O, T):
+    """The scan kernel picks its chunk length L (2..32 steps per lane) from T; exercise both
+    sides of every switch point, with a ragged NA mask so the general (non-dense) path runs."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(T, 1, 2, series_id=T)
+    y[T // 3:T // 3 + 5] = np.nan
+    y[0] = np.nan
+    y[T - 1] = np.nan
+    th0 = synth.make_init_packed(1, 2, 6, seed=T)
+    r = eng.em_batch(y, u, v, th0, niter=60, tol=1e-5, algo=2)
+    ref = _oracle_batch(O, y, u, v, th0, 60, 1e-5)
+    _assert_batch_parity(r, ref, "T=%d" % T)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("p", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("q", [1, 2, 4, 6, 8])
+def test_every_padded_input_size(eng, O, algo, p, q):
+    """All 16 (PP, QQ) kernel instantiations (rows padded to 1, 2, 4, 8), dense and masked."""
+    from ldsr_amd import synth
+    T = 150
+    y, u, v = synth.make_series(T, p, q, series_id=10 * p + q)
+    th0 = synth.make_init_packed(p, q, 5, seed=p * 8 + q)
+    for mask in ("dense", "scattered"):
+        ym = y.copy()
+        if mask == "scattered":
+            ym[np.random.default_rng(p + q).choice(T, 30, replace=False)] = np.nan
+        r = eng.em_batch(ym, u, v, th0, niter=40, tol=1e-5, algo=algo)
+        ref = _oracle_batch(O, ym, u, v, th0, 40, 1e-5)
+        _assert_batch_parity(r, ref, "p=%d q=%d %s" % (p, q, mask))
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("frac", [0.1, 0.5, 0.9])
+def test_scattered_missing_values(eng, O, algo, frac):
+    """NA scattered at random through the series (the reference branches per step, src/EM.cpp:82)."""
+    from ldsr_amd import synth
+    T = 1000
+    y, u, v = synth.make_series(T, 1, 2, series_id=31)
+    y[np.random.default_rng(int(frac * 10)).random(T) < frac] = np.nan
+    th0 = synth.make_init_packed(1, 2, 24, seed=12)
+    r = eng.em_batch(y, u, v, th0, niter=150, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 150, 1e-5)
+    _assert_batch_parity(r, ref, "scattered %.1f" % frac)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_fixed_niter_and_liks_trace(eng, O, algo):
     from ldsr_amd import synth
