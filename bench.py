@@ -160,10 +160,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
+    # Rehearsal on a one-GPU box: LDSR_BENCH_BACKEND=gloo LDSR_BENCH_ONE_GPU=1 lets several ranks
+    # share cuda:0 (the driver's real runs use one GPU per rank over RCCL).
+    backend = os.environ.get("LDSR_BENCH_BACKEND", "nccl")
+    if os.environ.get("LDSR_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ldsr_amd import _lib, shard, synth
     L = _lib.lib()
@@ -224,7 +232,7 @@ def main():
     assert np.all(st == 0), "non-finite likelihoods in the bench batch"
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
