@@ -14,6 +14,7 @@
  *                            also yields the winner's `fit` list of LDS_EM (src/EM.cpp:276-279)
  *   ldsr_mstep_batch         _ldsr_Mstep (src/RcppExports.cpp:26-38 -> src/EM.cpp:139-229)
  *   ldsr_propagate_batch     _ldsr_propagate (src/RcppExports.cpp:56-69 -> src/EM.cpp:295-356)
+ *   ldsr_penalized_lik_batch penalized_likelihood of R/LDS_GA.R:28-44 for a whole GA population
  *   ldsr_select_restart      the argmax-with-C>0 rule of R/LDS_reconstruction.R:50-58
  *
  * Data conventions (identical to the bytes R hands to .Call):
@@ -105,6 +106,14 @@ int ldsr_propagate_batch(int device, int n_series, int T, int p, int q, const do
                          const double *u, const double *v, int shared_uv,
                          const int *cell_offsets, const double *theta, int stdlik, double *X,
                          double *Y, double *V, double *lik);
+
+/* Batched penalized_likelihood (R/LDS_GA.R:28-44, the GA / BFGS fitness): for every theta,
+ * Kalman_smoother(..., stdlik = FALSE)$lik - lambda * sum_t (Xs[t+1] - A Xs[t] - B u[t])^2.
+ * pl: [n_cells].  Only the scalar leaves the device. */
+int ldsr_penalized_lik_batch(int device, int n_series, int T, int p, int q, const double *y,
+                             const double *u, const double *v, int shared_uv,
+                             const int *cell_offsets, const double *theta, double lambda,
+                             double *pl);
 
 /* Optional kernel timer.  While enabled, every ldsr_em_batch_device call brackets its EM
  * kernel with HIP events on the launch stream; collect() waits for them and returns the summed

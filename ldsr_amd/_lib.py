@@ -31,6 +31,8 @@ SIGNATURES = {
                                    C.c_int, _ip, _dp, _dp, _dp, _dp, _ip]),
     "ldsr_propagate_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                        C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "ldsr_penalized_lik_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                           C.c_int, _ip, _dp, C.c_double, _dp]),
     "ldsr_profile_enable": (None, [C.c_int]),
     "ldsr_profile_collect": (C.c_int, [_dp, _ip]),
     "ldsr_select_restart": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int]),

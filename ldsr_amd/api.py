@@ -164,6 +164,18 @@ def smooth_batch(y, u, v, theta, cell_offsets=None, stdlik=True, device=0, mode=
     return {"X": X, "Y": Yh, "V": Vv, "lik": lik}
 
 
+def penalized_likelihood(y, u, v, theta_packed, lam, cell_offsets=None, device=0):
+    """R/LDS_GA.R:28-44 for a batch of thetas [n, 6+p+q]: lik(stdlik=FALSE) - lam * ssq."""
+    Y, U, V, S, T, p, q, shared = _series(y, u, v)
+    theta = np.ascontiguousarray(np.atleast_2d(theta_packed), dtype=np.float64)
+    n = theta.shape[0]
+    off = np.ascontiguousarray([0, n] if cell_offsets is None else cell_offsets, dtype=np.int32)
+    pl = np.empty(n)
+    _lib.check(_lib.lib().ldsr_penalized_lik_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared,
+                                                   _i(off), _d(theta), float(lam), _d(pl)))
+    return pl
+
+
 def _dims(u, v):
     p = 1 if u is None else np.asarray(u).shape[-2]
     q = 1 if v is None else np.asarray(v).shape[-2]

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64) void smooth_kernel(SmoothParams prm) {
     if (prop) return;
 
     double Xs = Xu, Vs = Vu;
+    double ssq = 0.0;   // sum_t (Xs_{t+1} - A Xs_t - B u_t)^2, the penalty of R/LDS_GA.R:34-40
     J[T - 1] = Vu * th.A / (th.A * Vu * th.A + th.Q);  // src/EM.cpp:98
     {
         double dv = 0.0;
@@ -392,8 +393,13 @@ __global__ __launch_bounds__(64) void smooth_kernel(SmoothParams prm) {
         const double Xp1 = th.A * xu + bu;
         const double Vp1 = th.A * vu * th.A + th.Q;
         const double Jt = vu * th.A / Vp1;
+        const double Xs1 = Xs;
         Xs = xu + Jt * (Xs - Xp1);
         Vs = vu + Jt * (Vs - Vp1) * Jt;
+        {
+            const double d = Xs1 - th.A * Xs - bu;
+            ssq += d * d;
+        }
         double dv = 0.0;
 #pragma unroll
         for (int k = 0; k < QQ; k++) dv = fma(th.D[k], v[t * QQ + k], dv);
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(64) void smooth_kernel(SmoothParams prm) {
         J[t] = Jt;
         Y[t] = th.C * Xs + dv;
     }
+    if (prm.pen) prm.pen[cell] = lik - prm.lambda * ssq;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -317,12 +317,12 @@ extern "C" int ldsr_em_batch(int device, int n_series, int T, int p, int q, cons
 }
 
 // Shared driver of the smoother / propagate / mstep host entry points.
-// mode: 0 smoother, 1 propagate, 2 mstep
+// mode: 0 smoother, 1 propagate, 2 mstep, 3 penalized likelihood (smoother, scalar output only)
 static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int q, const double *y,
                           const double *u, const double *v, int shared_uv,
                           const int *cell_offsets, const double *theta_in, int stdlik, double *X,
                           double *Y, double *V, double *J, double *lik, double *theta_out,
-                          int *status) {
+                          int *status, double lambda = 0.0) {
     int rc = check_common(n_series, T, p, q, y, cell_offsets);
     if (rc) return rc;
     const int n_cells = cell_offsets[n_series];
@@ -348,7 +348,8 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     SmoothParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.T = T; sp.p = p; sp.q = q; sp.has_u = u != nullptr; sp.has_v = v != nullptr;
-    sp.n_cells = n_cells; sp.stdlik = stdlik; sp.mode = mode;
+    sp.n_cells = n_cells; sp.stdlik = stdlik; sp.mode = (mode == 3) ? 0 : mode;
+    sp.lambda = lambda;
     sp.yp = (const double *)(ws + L.yp);
     sp.up = (const double *)(ws + L.up);
     sp.vp = (const double *)(ws + L.vp);
@@ -383,8 +384,17 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     if (!theta_in || !lik) return fail(LDSR_EINVAL, "theta and lik must not be NULL");
     HIPCHK(hipMemcpy(d_theta, theta_in, sizeof(double) * (size_t)n_cells * P, hipMemcpyHostToDevice));
     sp.theta = d_theta;
+    double *d_pen = nullptr;
+    if (mode == 3) {
+        HIPCHK(B.alloc(&d_pen, (size_t)n_cells));
+        sp.pen = d_pen;
+    }
     HIPCHK(launch_smooth(sp, PP, QQ, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
+    if (mode == 3) {
+        HIPCHK(hipMemcpy(lik, d_pen, sizeof(double) * (size_t)n_cells, hipMemcpyDeviceToHost));
+        return LDSR_OK;
+    }
     if (X) HIPCHK(hipMemcpy(X, d_X, sizeof(double) * nT, hipMemcpyDeviceToHost));
     if (Y) HIPCHK(hipMemcpy(Y, d_Y, sizeof(double) * nT, hipMemcpyDeviceToHost));
     if (V) HIPCHK(hipMemcpy(V, d_V, sizeof(double) * nT, hipMemcpyDeviceToHost));
@@ -399,6 +409,14 @@ extern "C" int ldsr_smooth_batch(int device, int n_series, int T, int p, int q, 
                                  double *X, double *Y, double *V, double *J, double *lik) {
     return run_fit_kernel(0, device, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta,
                           stdlik, X, Y, V, J, lik, nullptr, nullptr);
+}
+
+extern "C" int ldsr_penalized_lik_batch(int device, int n_series, int T, int p, int q,
+                                        const double *y, const double *u, const double *v,
+                                        int shared_uv, const int *cell_offsets, const double *theta,
+                                        double lambda, double *pl) {
+    return run_fit_kernel(3, device, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta, 0,
+                          nullptr, nullptr, nullptr, nullptr, pl, nullptr, nullptr, lambda);
 }
 
 extern "C" int ldsr_propagate_batch(int device, int n_series, int T, int p, int q, const double *y,

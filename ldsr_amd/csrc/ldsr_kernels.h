@@ -21,6 +21,8 @@ struct SmoothParams {
     double *X, *Y, *V, *J, *lik;
     double *theta_out;    // mstep
     int *status;
+    double *pen;          // smoother: lik - lambda * ssq (penalized_likelihood), may be null
+    double lambda;
 };
 
 static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
