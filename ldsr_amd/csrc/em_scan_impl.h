@@ -45,12 +45,6 @@ __device__ __forceinline__ double uniform_d(double x) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
-}
-
 // All-reduce N independent sums with ONE dependent chain of 6 cross-lane rounds: every round
 // issues all N exchanges before the N adds (a per-value butterfly would serialise 6*N LDS
 // round-trips).  The summation tree is fixed, so results are run-to-run deterministic and
@@ -65,12 +59,6 @@ __device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
 #pragma unroll
         for (int i = 0; i < N; i++) x[i] += t[i];
     }
-}
-
-__device__ __forceinline__ double wave_min(double x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x = fmin(x, __shfl_xor(x, d, 64));
-    return x;
 }
 
 // Structured 3x3 step / composite matrix [[m00 m01 0],[m10 m11 0],[m20 m21 m22]].
@@ -145,18 +133,6 @@ __device__ __forceinline__ PMat pdpp(const PMat &m) {
     r.m20 = dppd<CTRL, RM>(0.0, m.m20);
     r.m21 = dppd<CTRL, RM>(0.0, m.m21);
     r.m22 = dppd<CTRL, RM>(1.0, m.m22);
-    return r;
-}
-
-__device__ __forceinline__ PMat pshfl_up(const PMat &m, int d) {
-    PMat r;
-    r.m00 = __shfl_up(m.m00, d, 64);
-    r.m01 = __shfl_up(m.m01, d, 64);
-    r.m10 = __shfl_up(m.m10, d, 64);
-    r.m11 = __shfl_up(m.m11, d, 64);
-    r.m20 = __shfl_up(m.m20, d, 64);
-    r.m21 = __shfl_up(m.m21, d, 64);
-    r.m22 = __shfl_up(m.m22, d, 64);
     return r;
 }
 
@@ -276,17 +252,26 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         const double rR = fast_rcp(R);
         const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
 
+        // e_t = y_t - D v_t (innovation minus C Xp) and bu_t = B u_t of step j of this lane, from LDS
+        auto e_at = [&](int j) {
+            double e = ys[j * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+            return e;
+        };
+        auto bu_at = [&](int j) {
+            double bu = 0.0;
+#pragma unroll
+            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            return bu;
+        };
+
         // ------------------------------------------------ F1: compose this lane's step matrices
         PMat M;
         M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
         auto f1 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            double e = ys[j * 64 + lane];
-#pragma unroll
-            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
-            double bu = 0.0;
-#pragma unroll
-            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            const double e = e_at(j), bu = bu_at(j);
             const double a00 = o ? alpha : A2;
             const double g = o ? C2R : 0.0;
             const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
@@ -354,12 +339,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         double Pi = 1.0, G = 0.0, H = 0.0;                     // reverse composite (HS > 0 only)
         auto f2 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            double e = ys[j * 64 + lane];
-#pragma unroll
-            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
-            double bu = 0.0;
-#pragma unroll
-            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            const double e = e_at(j), bu = bu_at(j);
             const double r = o ? r0 : 0.0;             // 1/Sigma_t; 0 = "no update" (:82-84)
             const double sl = o ? sg : 1.0;
             sprod *= sl;
@@ -514,12 +494,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             double Xq = Xp0, Vq = Vp0, sgq = sg0, rq = r00;
             auto f2r = [&](int j) {
                 const bool o = DENSE || ((obsmask >> j) & 1u);
-                double e = ys[j * 64 + lane];
-#pragma unroll
-                for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
-                double bu = 0.0;
-#pragma unroll
-                for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+                const double e = e_at(j), bu = bu_at(j);
                 const double r = o ? rq : 0.0;
                 const double w = Vq * r;
                 const double K = C * w;
