@@ -444,3 +444,18 @@ def test_config2_full_size(eng, O, algo):
     idx = np.arange(0, 4096, 16)
     ref = _oracle_batch(O, y, u, v, th0[idx], 100, 0.0, threads=16)
     _assert_batch_parity({k: r[k][idx] for k in ("theta", "lik", "n_iter")}, ref, "cfg2 full")
+
+
+@pytest.mark.parametrize("algo", [2])
+@pytest.mark.parametrize("mask", ["dense", "paleo"])
+def test_config2_full_size_converged_all_cells(eng, O, algo, mask):
+    """Config 2 as the survey specifies its parity run (niter=1000, tol=1e-5): EVERY one of the
+    4096 cells must stop at the oracle's iteration and agree on theta and lik."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(1000, 1, 2, series_id=0, mask=mask)
+    th0 = synth.make_init_packed(1, 2, 4096, seed=1)
+    r = eng.em_batch(y, u, v, th0, niter=1000, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 1000, 1e-5, threads=16)
+    assert np.all(np.isfinite(ref[1]))
+    _assert_batch_parity(r, ref, "cfg2 converged %s" % mask)
+    assert eng.select_restart(r["lik"], r["theta"], 1, 2) == O.select(ref[1], ref[0][:, 2])
