@@ -8,6 +8,7 @@
  *                            of R/LDS_reconstruction.R:46, i.e. n_cells calls of
  *                            _ldsr_LDS_EM (src/RcppExports.cpp:40-53 -> src/EM.cpp:245-280),
  *                            batched over restarts and over series / CV folds
+ *   ldsr_em_batch_multi      same, sharded over several GPUs by host threads (no collective)
  *   ldsr_em_batch_device     same, operands already resident in HBM (bench + torch callers)
  *   ldsr_smooth_batch        _ldsr_Kalman_smoother (src/RcppExports.cpp:11-24 ->
  *                            src/EM.cpp:22-131), one E-step per (series, theta) cell;
@@ -38,8 +39,8 @@
  * unconditionally, src/EM.cpp:256).
  *
  * Every function returns LDSR_OK (0) or an error code; ldsr_last_error() gives the
- * message of the calling thread's last failure.  Nothing is retained between calls
- * except a per-device workspace cache freed by ldsr_shutdown().
+ * message of the calling thread's last failure.  Nothing is retained between calls except the
+ * optional kernel-timer events, freed by ldsr_shutdown().
  */
 #ifndef LDSR_HIP_H
 #define LDSR_HIP_H
@@ -76,6 +77,16 @@ int ldsr_em_batch(int device, int n_series, int T, int p, int q, const double *y
                   const double *u, const double *v, int shared_uv, const int *cell_offsets,
                   const double *theta0, int niter, double tol, int algo,
                   double *theta, double *lik, int *n_iter, int *status, double *liks);
+
+/* Same over several GPUs of one node: the cell grid is cut into n_devices contiguous slices,
+ * one host thread per listed device, no collective (restarts never communicate,
+ * R/LDS_reconstruction.R:46).  devices[] may repeat an id.  This is what the R shim calls with
+ * devices = 0 .. ldsr_device_count()-1. */
+int ldsr_em_batch_multi(int n_devices, const int *devices, int n_series, int T, int p, int q,
+                        const double *y, const double *u, const double *v, int shared_uv,
+                        const int *cell_offsets, const double *theta0, int niter, double tol,
+                        int algo, double *theta, double *lik, int *n_iter, int *status,
+                        double *liks);
 
 /* Same with DEVICE pointers (cell_offsets stays a host array).  Asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = default stream).  workspace: device buffer of at

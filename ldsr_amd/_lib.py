@@ -21,6 +21,9 @@ SIGNATURES = {
     "ldsr_em_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                 C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _ip,
                                 _ip, _dp]),
+    "ldsr_em_batch_multi": (C.c_int, [C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                      C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp,
+                                      _ip, _ip, _dp]),
     "ldsr_em_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldsr_em_batch_device": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                        _vp, C.c_int, _ip, _vp, C.c_int, C.c_double, C.c_int, _vp,

@@ -113,10 +113,11 @@ def _series(y, u, v):
 
 
 def em_batch(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, device=0, algo=ALGO_AUTO,
-             return_liks=False):
+             return_liks=False, devices=None):
     """All cells in one launch.  theta0: packed [n_cells, 6+p+q].  cell_offsets: [S+1]
     (default: every cell belongs to series 0).  Returns dict of arrays theta, lik, n_iter,
-    status (and liks [n_cells, niter], NaN padded)."""
+    status (and liks [n_cells, niter], NaN padded).  devices=[0,1,...] shards the cells over
+    several GPUs inside the library (host threads, no collective)."""
     Y, U, V, S, T, p, q, shared = _series(y, u, v)
     theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
     if theta0.ndim != 2 or theta0.shape[1] != 6 + p + q:
@@ -135,9 +136,15 @@ def em_batch(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, device=0,
     status = np.empty(n, dtype=np.int32)
     liks = np.empty((n, niter)) if return_liks else None
     L = _lib.lib()
-    _lib.check(L.ldsr_em_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off),
-                               _d(theta0), int(niter), float(tol), int(algo), _d(theta), _d(lik),
-                               _i(n_iter), _i(status), _d(liks)))
+    if devices is not None:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _lib.check(L.ldsr_em_batch_multi(devs.size, _i(devs), S, T, p, q, _d(Y), _d(U), _d(V), shared,
+                                         _i(off), _d(theta0), int(niter), float(tol), int(algo),
+                                         _d(theta), _d(lik), _i(n_iter), _i(status), _d(liks)))
+    else:
+        _lib.check(L.ldsr_em_batch(device, S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off),
+                                   _d(theta0), int(niter), float(tol), int(algo), _d(theta), _d(lik),
+                                   _i(n_iter), _i(status), _d(liks)))
     out = {"theta": theta, "lik": lik, "n_iter": n_iter, "status": status}
     if return_liks:
         out["liks"] = liks

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldsr_hip.h"
@@ -313,6 +314,58 @@ extern "C" int ldsr_em_batch(int device, int n_series, int T, int p, int q, cons
     HIPCHK(hipMemcpy(status, d_status, sizeof(int) * (size_t)n_cells, hipMemcpyDeviceToHost));
     if (liks)
         HIPCHK(hipMemcpy(liks, d_liks, sizeof(double) * (size_t)n_cells * niter, hipMemcpyDeviceToHost));
+    return LDSR_OK;
+}
+
+// Multi-GPU form of ldsr_em_batch: the cell grid is cut into contiguous slices, one host thread
+// per listed device runs its slice through ldsr_em_batch (cells are grouped by series, so a slice
+// is a contiguous range of series: plain pointer offsets, no gather).  No collective; results
+// land directly in the caller's arrays.  The same device may be listed more than once.
+extern "C" int ldsr_em_batch_multi(int n_devices, const int *devices, int n_series, int T, int p,
+                                   int q, const double *y, const double *u, const double *v,
+                                   int shared_uv, const int *cell_offsets, const double *theta0,
+                                   int niter, double tol, int algo, double *theta, double *lik,
+                                   int *n_iter, int *status, double *liks) {
+    if (n_devices < 1 || !devices) return fail(LDSR_EINVAL, "n_devices must be >= 1");
+    int rc = check_common(n_series, T, p, q, y, cell_offsets);
+    if (rc) return rc;
+    if (niter < 2) return fail(LDSR_EINVAL, "niter must be >= 2 (the reference reads lik[1], src/EM.cpp:256)");
+    if (!theta0 || !theta || !lik || !n_iter || !status) return fail(LDSR_EINVAL, "NULL pointer");
+    const int n_cells = cell_offsets[n_series];
+    const int P = 6 + p + q;
+    std::vector<int> rcs((size_t)n_devices, LDSR_OK);
+    std::vector<std::string> msgs((size_t)n_devices);
+    std::vector<std::thread> pool;
+    for (int d = 0; d < n_devices; d++) {
+        const int lo = (int)((long long)n_cells * d / n_devices);
+        const int hi = (int)((long long)n_cells * (d + 1) / n_devices);
+        if (hi <= lo) continue;
+        pool.emplace_back([=, &rcs, &msgs]() {
+            // series range [s0, s1) that owns cells [lo, hi), and the clipped local offsets
+            int s0 = 0;
+            while (cell_offsets[s0 + 1] <= lo) s0++;
+            int s1 = s0;
+            while (s1 < n_series && cell_offsets[s1] < hi) s1++;
+            std::vector<int> off((size_t)(s1 - s0) + 1);
+            for (int s = s0; s <= s1; s++) {
+                int c = cell_offsets[s];
+                c = c < lo ? lo : (c > hi ? hi : c);
+                off[(size_t)(s - s0)] = c - lo;
+            }
+            const size_t uo = shared_uv ? 0 : (size_t)s0 * T * p, vo = shared_uv ? 0 : (size_t)s0 * T * q;
+            const int r = ldsr_em_batch(devices[d], s1 - s0, T, p, q, y + (size_t)s0 * T,
+                                        u ? u + uo : nullptr, v ? v + vo : nullptr, shared_uv,
+                                        off.data(), theta0 + (size_t)lo * P, niter, tol, algo,
+                                        theta + (size_t)lo * P, lik + lo, n_iter + lo, status + lo,
+                                        liks ? liks + (size_t)lo * niter : nullptr);
+            rcs[(size_t)d] = r;
+            if (r) msgs[(size_t)d] = ldsr_last_error();   // thread-local message of this worker
+        });
+    }
+    for (auto &t : pool) t.join();
+    for (int d = 0; d < n_devices; d++)
+        if (rcs[(size_t)d])
+            return fail(rcs[(size_t)d], "device " + std::to_string(devices[d]) + ": " + msgs[(size_t)d]);
     return LDSR_OK;
 }
 

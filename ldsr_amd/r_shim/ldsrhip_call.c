@@ -81,9 +81,15 @@ SEXP ldsrhip_LDS_EM_batch(SEXP y, SEXP u, SEXP v, SEXP init, SEXP niterS, SEXP t
     int *n_iter = (int *)R_alloc(n, sizeof(int)), *status = (int *)R_alloc(n, sizeof(int));
     const int off[2] = {0, n};
     R_CheckUserInterrupt(); /* the reference polls every 100 iterations (src/EM.cpp:261-262) */
-    int rc = ldsr_em_batch(0, 1, T, p, q, REAL(y), has_u ? REAL(u) : NULL, has_v ? REAL(v) : NULL,
-                           0, off, th0, niter, tol, LDSR_ALGO_AUTO, theta, lik, n_iter, status, liks);
-    if (rc != LDSR_OK) Rf_error("ldsr_em_batch: %s", ldsr_last_error());
+    int n_dev = ldsr_device_count(); /* restarts shard over every GPU of the node, no collective */
+    if (n_dev < 1) Rf_error("ldsrhip: no ROCm device visible");
+    if (n_dev > n) n_dev = n;
+    int *devs = (int *)R_alloc(n_dev, sizeof(int));
+    for (int d = 0; d < n_dev; d++) devs[d] = d;
+    int rc = ldsr_em_batch_multi(n_dev, devs, 1, T, p, q, REAL(y), has_u ? REAL(u) : NULL,
+                                 has_v ? REAL(v) : NULL, 0, off, th0, niter, tol, LDSR_ALGO_AUTO,
+                                 theta, lik, n_iter, status, liks);
+    if (rc != LDSR_OK) Rf_error("ldsr_em_batch_multi: %s", ldsr_last_error());
     for (int c = 0; c < n; c++)
         if (status[c] == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular"); /* arma::inv throws */
     const int k = ldsr_select_restart(n, lik, theta, p, q); /* R/LDS_reconstruction.R:50-58 */

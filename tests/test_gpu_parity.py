@@ -459,3 +459,32 @@ def test_config2_full_size_converged_all_cells(eng, O, algo, mask):
     assert np.all(np.isfinite(ref[1]))
     _assert_batch_parity(r, ref, "cfg2 converged %s" % mask)
     assert eng.select_restart(r["lik"], r["theta"], 1, 2) == O.select(ref[1], ref[0][:, 2])
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 3, 5])
+def test_multi_device_entry_is_bit_identical(eng, n_dev):
+    """ldsr_em_batch_multi: host threads, one contiguous cell slice per listed device (here the
+    one GPU of the box listed n_dev times); results must be bit-identical to the single call,
+    whatever the cut points (ragged series, shared and own inputs, an empty series)."""
+    from ldsr_amd import synth
+    T, p, q, S = 200, 1, 3, 4
+    ys, us, vs = zip(*[synth.make_series(T, p, q, series_id=300 + s, mask="paleo", n_tail=50 + 20 * s)
+                       for s in range(S)])
+    Y, U, V = np.stack(ys), np.stack(us), np.stack(vs)
+    counts = [7, 0, 11, 5]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    th0 = synth.make_init_packed(p, q, int(off[-1]), seed=6)
+    for uu, vv in ((U, V), (us[0], vs[0])):            # own inputs, then shared inputs
+        one = eng.em_batch(Y, uu, vv, th0, cell_offsets=off, niter=60, tol=1e-5, return_liks=True)
+        multi = eng.em_batch(Y, uu, vv, th0, cell_offsets=off, niter=60, tol=1e-5, return_liks=True,
+                             devices=[0] * n_dev)
+        for k in ("theta", "lik", "n_iter", "status", "liks"):
+            assert np.array_equal(one[k], multi[k], equal_nan=True), (n_dev, k)
+
+
+def test_multi_device_entry_reports_bad_device(eng):
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(50, 1, 2)
+    with pytest.raises(Exception) as e:
+        eng.em_batch(y, u, v, synth.make_init_packed(1, 2, 8), niter=5, devices=[0, 99])
+    assert "device 99" in str(e.value)
