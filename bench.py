@@ -91,12 +91,14 @@ def bytes_per_unit(T, p, q):
     return 16 * T * (3 + p + q)
 
 
-def load_pmc_traffic(workload):
-    """HBM bytes per EM-kernel launch from the committed rocprofv3 --pmc summary, or None."""
+def load_pmc(workload, key):
+    """A value of the committed rocprofv3 --pmc summary (profiles/pmc_summary.json), or None.
+    PMC counters cannot be collected from inside the timed run; they come from separate
+    rocprofv3 passes of this same command and are committed under profiles/."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(workload, {}).get(key)
     except (OSError, ValueError):
         return None
 
@@ -142,8 +144,8 @@ def cpu_baseline(p, q, niter, Y, U, V, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan")
     ap.add_argument("--mask", default="dense", choices=["dense", "paleo"])
@@ -259,13 +261,15 @@ def main():
                        "sharding": "contiguous cell ranges over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc_traffic(args.workload),
+                         "traffic": load_pmc(args.workload, "hbm_bytes_per_launch"),
+                         "valu_busy_frac": load_pmc(args.workload, "valu_busy_frac"),
                          "kernel": "em_scan_kernel" if args.algo != 1 else "em_serial_kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_unit": bpu,
                          "units_per_launch": cells * niter,
                          "note": "algorithmic (logical) traffic; the series is served from LDS "
                                  "and the filtered states never leave registers, so measured "
-                                 "HBM traffic is far below it"},
+                                 "HBM traffic (traffic, bytes per launch, PMC) is far below it; "
+                                 "the binding resource is fp64 VALU issue (valu_busy_frac, PMC)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)
