@@ -488,3 +488,39 @@ def test_multi_device_entry_reports_bad_device(eng):
     with pytest.raises(Exception) as e:
         eng.em_batch(y, u, v, synth.make_init_packed(1, 2, 8), niter=5, devices=[0, 99])
     assert "device 99" in str(e.value)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_degenerate_initial_thetas_do_not_trap(eng, O, algo):
+    """Nothing clamps Q or R in the reference (src/EM.cpp:177,210) and NaN likelihoods are
+    tolerated by the selection (na.rm, R/LDS_reconstruction.R:54).  Hostile inits must come back
+    with a status word, never hang or fault, and must not disturb their healthy neighbours."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(300, 1, 2, series_id=8)
+    th0 = synth.make_init_packed(1, 2, 16, seed=5)
+    P = th0.shape[1]
+    iQ, iR, iV1, iC, iA = 5, 6, 8, 2, 0
+    th0[1, :] = np.nan                    # all NaN
+    th0[3, iR] = np.nan
+    th0[5, iR] = -1.0                     # negative R: log(Sigma) of a negative number
+    th0[7, iQ] = 0.0; th0[7, iV1] = 0.0   # zero variances: 0/0 in the smoother gain
+    th0[9, iA] = np.inf
+    th0[11, iC] = 0.0                     # y carries no information about x at iteration 0
+    th0[13, iQ] = 1e300; th0[13, iR] = 1e-300
+    r = eng.em_batch(y, u, v, th0, niter=40, tol=1e-5, algo=algo)
+    ref = _oracle_batch(O, y, u, v, th0, 40, 1e-5)
+    assert r["theta"].shape == (16, P)
+    healthy = [0, 2, 4, 6, 8, 10, 12, 14, 15]
+    assert np.all(np.isfinite(ref[1][healthy]))
+    _assert_batch_parity({k: r[k][healthy] for k in ("theta", "lik", "n_iter")},
+                         tuple(a[healthy] for a in ref), "healthy neighbours")
+    for c in (1, 3, 9):                   # NaN / Inf inputs can only give NaN
+        assert np.isnan(r["lik"][c]) and r["status"][c] == 1 and np.isnan(ref[1][c])
+    assert np.all((r["status"] == 0) == np.isfinite(r["lik"]))
+    # wherever the oracle stays finite the GPU result must be finite and equal (cell 13 is
+    # excluded: with Q = 1e300 the factor 1 - K C sits in the last bit and FMA contraction
+    # decides its sign; it only has to come back with a status)
+    for c in (5, 7, 11):
+        if np.isfinite(ref[1][c]) and np.all(np.isfinite(ref[0][c])):
+            assert r["n_iter"][c] == ref[2][c], c
+            assert parity_close(r["lik"][c], ref[1][c], 1e-6, 1e-9), c
