@@ -34,8 +34,9 @@
  *   cell_offsets [n_series+1]   HOST array: cells [cell_offsets[s], cell_offsets[s+1]) are
  *                               the restarts of series s
  *
- * Limits of this build: 1 <= p, q <= 8 (every BASELINE config and the reference's tests;
- * larger returns LDSR_EUNSUPPORTED), T >= 2, niter >= 2 (the reference indexes lik[1]
+ * Limits of this build: 1 <= p, q <= 16 (larger returns LDSR_EUNSUPPORTED; the scan kernel
+ * covers p, q <= 8 = every BASELINE config and the reference's tests, wider inputs run on the
+ * serial kernel), T >= 2, niter >= 2 (the reference indexes lik[1]
  * unconditionally, src/EM.cpp:256).
  *
  * Every function returns LDSR_OK (0) or an error code; ldsr_last_error() gives the
@@ -64,7 +65,7 @@ extern "C" {
 /* algorithm selector */
 #define LDSR_ALGO_AUTO 0
 #define LDSR_ALGO_SERIAL 1 /* one thread per cell, sequential in time (any T) */
-#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 64*32) */
+#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 2048, p, q <= 8) */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);

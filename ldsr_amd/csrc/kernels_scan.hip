@@ -13,7 +13,7 @@ static int scan_L_for(int T) {
 
 bool em_scan_supported(int T, int PP, int QQ) {
     const int L = scan_L_for(T);
-    if (!L) return false;
+    if (!L || PP > 8 || QQ > 8) return false;   // instantiated for padded widths up to 8
     return (size_t)64 * L * (1 + PP + QQ) * sizeof(double) <= 160 * 1024;
 }
 

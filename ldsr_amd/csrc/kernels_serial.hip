@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     }
     // identity / zero padding of the statistics
     for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
-        const double id = ((i >> 3) == (i & 7)) ? 1.0 : 0.0;
+        const double id = ((i / LDSR_MAXPQ) == (i % LDSR_MAXPQ)) ? 1.0 : 0.0;
         sc.Svv_inv[i] = id;
         sc.Tuu_inv[i] = id;
     }
@@ -477,23 +477,32 @@ __global__ __launch_bounds__(64) void mstep_kernel(SmoothParams prm) {
 // launchers (dispatch on padded sizes)
 // ---------------------------------------------------------------------------------------
 #define DISPATCH_PQ(PPv, QQv, CALL)                                                     \
-    switch ((PPv) * 16 + (QQv)) {                                                       \
-        case 1 * 16 + 1: { constexpr int PP = 1, QQ = 1; CALL; } break;                 \
-        case 1 * 16 + 2: { constexpr int PP = 1, QQ = 2; CALL; } break;                 \
-        case 1 * 16 + 4: { constexpr int PP = 1, QQ = 4; CALL; } break;                 \
-        case 1 * 16 + 8: { constexpr int PP = 1, QQ = 8; CALL; } break;                 \
-        case 2 * 16 + 1: { constexpr int PP = 2, QQ = 1; CALL; } break;                 \
-        case 2 * 16 + 2: { constexpr int PP = 2, QQ = 2; CALL; } break;                 \
-        case 2 * 16 + 4: { constexpr int PP = 2, QQ = 4; CALL; } break;                 \
-        case 2 * 16 + 8: { constexpr int PP = 2, QQ = 8; CALL; } break;                 \
-        case 4 * 16 + 1: { constexpr int PP = 4, QQ = 1; CALL; } break;                 \
-        case 4 * 16 + 2: { constexpr int PP = 4, QQ = 2; CALL; } break;                 \
-        case 4 * 16 + 4: { constexpr int PP = 4, QQ = 4; CALL; } break;                 \
-        case 4 * 16 + 8: { constexpr int PP = 4, QQ = 8; CALL; } break;                 \
-        case 8 * 16 + 1: { constexpr int PP = 8, QQ = 1; CALL; } break;                 \
-        case 8 * 16 + 2: { constexpr int PP = 8, QQ = 2; CALL; } break;                 \
-        case 8 * 16 + 4: { constexpr int PP = 8, QQ = 4; CALL; } break;                 \
-        case 8 * 16 + 8: { constexpr int PP = 8, QQ = 8; CALL; } break;                 \
+    switch ((PPv) * 32 + (QQv)) {                                                       \
+        case 1 * 32 + 1: { constexpr int PP = 1, QQ = 1; CALL; } break;               \
+        case 1 * 32 + 2: { constexpr int PP = 1, QQ = 2; CALL; } break;               \
+        case 1 * 32 + 4: { constexpr int PP = 1, QQ = 4; CALL; } break;               \
+        case 1 * 32 + 8: { constexpr int PP = 1, QQ = 8; CALL; } break;               \
+        case 1 * 32 + 16: { constexpr int PP = 1, QQ = 16; CALL; } break;               \
+        case 2 * 32 + 1: { constexpr int PP = 2, QQ = 1; CALL; } break;               \
+        case 2 * 32 + 2: { constexpr int PP = 2, QQ = 2; CALL; } break;               \
+        case 2 * 32 + 4: { constexpr int PP = 2, QQ = 4; CALL; } break;               \
+        case 2 * 32 + 8: { constexpr int PP = 2, QQ = 8; CALL; } break;               \
+        case 2 * 32 + 16: { constexpr int PP = 2, QQ = 16; CALL; } break;               \
+        case 4 * 32 + 1: { constexpr int PP = 4, QQ = 1; CALL; } break;               \
+        case 4 * 32 + 2: { constexpr int PP = 4, QQ = 2; CALL; } break;               \
+        case 4 * 32 + 4: { constexpr int PP = 4, QQ = 4; CALL; } break;               \
+        case 4 * 32 + 8: { constexpr int PP = 4, QQ = 8; CALL; } break;               \
+        case 4 * 32 + 16: { constexpr int PP = 4, QQ = 16; CALL; } break;               \
+        case 8 * 32 + 1: { constexpr int PP = 8, QQ = 1; CALL; } break;               \
+        case 8 * 32 + 2: { constexpr int PP = 8, QQ = 2; CALL; } break;               \
+        case 8 * 32 + 4: { constexpr int PP = 8, QQ = 4; CALL; } break;               \
+        case 8 * 32 + 8: { constexpr int PP = 8, QQ = 8; CALL; } break;               \
+        case 8 * 32 + 16: { constexpr int PP = 8, QQ = 16; CALL; } break;               \
+        case 16 * 32 + 1: { constexpr int PP = 16, QQ = 1; CALL; } break;               \
+        case 16 * 32 + 2: { constexpr int PP = 16, QQ = 2; CALL; } break;               \
+        case 16 * 32 + 4: { constexpr int PP = 16, QQ = 4; CALL; } break;               \
+        case 16 * 32 + 8: { constexpr int PP = 16, QQ = 8; CALL; } break;               \
+        case 16 * 32 + 16: { constexpr int PP = 16, QQ = 16; CALL; } break;               \
         default: return hipErrorInvalidValue;                                           \
     }
 

@@ -128,7 +128,7 @@ static int check_common(int n_series, int T, int p, int q, const double *y,
     if (T < 2) return fail(LDSR_EINVAL, "T must be >= 2");
     if (p < 1 || q < 1) return fail(LDSR_EINVAL, "p and q must be >= 1 (use 1 with u/v = NULL for an absent input)");
     if (p > LDSR_MAXPQ || q > LDSR_MAXPQ)
-        return fail(LDSR_EUNSUPPORTED, "p and q above 8 are not supported by this build");
+        return fail(LDSR_EUNSUPPORTED, "p and q above 16 are not supported by this build");
     if (!y || !cell_offsets) return fail(LDSR_EINVAL, "y and cell_offsets must not be NULL");
     if (cell_offsets[0] != 0) return fail(LDSR_EINVAL, "cell_offsets[0] must be 0");
     for (int s = 0; s < n_series; s++)

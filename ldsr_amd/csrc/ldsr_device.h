@@ -3,14 +3,14 @@
 // Model (reference: /root/reference/src/EM.cpp:20 "one dimensional state and output"):
 //   x_{t+1} = A x_t + B u_t + w_t,  w ~ N(0,Q)         y_t = C x_t + D v_t + e_t,  e ~ N(0,R)
 // p = rows of u, q = rows of v.  Kernels are instantiated on padded sizes PP, QQ in
-// {1,2,4,8}; padded rows of u / v are zero, so they contribute nothing to any sum, and the
+// {1,2,4,8,16} (scan kernel: up to 8); padded rows of u / v are zero, so they contribute nothing to any sum, and the
 // per-series inverse blocks are padded with identity so the padded B / D entries solve to 0.
 // An absent u (v) is the same thing with p (q) = 1 and an all-zero row, which reproduces
 // the reference's absent-input branches (src/EM.cpp:71-75,172,212-213) exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define LDSR_MAXPQ 8
+#define LDSR_MAXPQ 16   // widest u / v (rows); the scan kernel is instantiated up to 8
 
 // Theta-independent statistics of one (series, NA mask): computed once by series_prep_kernel.
 // The reference recomputes Svv, Syv, Tuu on every Mstep call (src/EM.cpp:158-161,193).

@@ -25,7 +25,7 @@ struct SmoothParams {
     double lambda;
 };
 
-static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16; }
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream);
 hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);

@@ -50,8 +50,8 @@ def test_argument_validation_without_gpu():
     # T < 2
     rc = L.ldsr_em_batch(0, 1, 1, 1, 1, y, None, None, 0, off, th, 10, 1e-5, 0, out, lik, it, st, None)
     assert rc == 1 and b"T must be" in L.ldsr_last_error()
-    # p > 8
-    rc = L.ldsr_em_batch(0, 1, 4, 9, 1, y, None, None, 0, off, th, 10, 1e-5, 0, out, lik, it, st, None)
+    # p > 16
+    rc = L.ldsr_em_batch(0, 1, 4, 17, 1, y, None, None, 0, off, th, 10, 1e-5, 0, out, lik, it, st, None)
     assert rc == 2
     # niter < 2: the reference reads lik[1] unconditionally (src/EM.cpp:256)
     rc = L.ldsr_em_batch(0, 1, 4, 1, 1, y, None, None, 0, off, th, 1, 1e-5, 0, out, lik, it, st, None)
@@ -61,7 +61,8 @@ def test_argument_validation_without_gpu():
     rc = L.ldsr_em_batch(0, 1, 4, 1, 1, y, None, None, 0, bad, th, 10, 1e-5, 0, out, lik, it, st, None)
     assert rc == 1
     assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 0) > 0
-    assert L.ldsr_em_workspace_bytes(1, 1000, 9, 2, 4096, 0) == 0
+    assert L.ldsr_em_workspace_bytes(1, 1000, 17, 2, 4096, 0) == 0
+    assert L.ldsr_em_workspace_bytes(1, 1000, 12, 2, 64, 0) > 2 * 1000 * 64 * 8    # wide input: serial kernel
     # serial needs the [t][cell] strip, scan does not
     assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 1) >= 2 * 1000 * 4096 * 8
     assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 2) < 1 << 20

@@ -262,6 +262,26 @@ def test_every_padded_input_size(eng, O, algo, p, q):
         _assert_batch_parity(r, ref, "p=%d q=%d %s" % (p, q, mask))
 
 
+@pytest.mark.parametrize("p,q", [(9, 2), (3, 12), (16, 16), (11, 13)])
+def test_wide_inputs_run_on_the_serial_kernel(eng, O, p, q):
+    """More than 8 rows of u or v: LDSR_ALGO_AUTO falls back to the serial kernel, the scan
+    kernel refuses; the standalone smoother / M-step take the same widths."""
+    from ldsr_amd import synth
+    T = 120
+    y, u, v = synth.make_series(T, p, q, series_id=p * 17 + q, mask="paleo", n_tail=80)
+    th0 = synth.make_init_packed(p, q, 6, seed=p + q)
+    with pytest.raises(Exception):
+        eng.em_batch(y, u, v, th0, niter=30, tol=1e-5, algo=2)
+    r = eng.em_batch(y, u, v, th0, niter=30, tol=1e-5)
+    ref = _oracle_batch(O, y, u, v, th0, 30, 1e-5)
+    _assert_batch_parity(r, ref, "wide p=%d q=%d" % (p, q))
+    s = eng.Kalman_smoother(y, u, v, th0[0])
+    so = O.kalman_smoother(y, u, v, th0[0])
+    assert parity_close(s["X"][0], so["X"], RTOL, ATOL) and parity_close(s["lik"], so["lik"], RTOL, ATOL)
+    th1 = eng.pack_theta(eng.Mstep(y, u, v, s), p, q)
+    assert parity_close(th1, O.mstep(y, u, v, so), RTOL, ATOL)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("frac", [0.1, 0.5, 0.9])
 def test_scattered_missing_values(eng, O, algo, frac):
@@ -416,7 +436,7 @@ def test_argument_errors(eng):
     with pytest.raises(Exception):
         eng.em_batch(y, u, v, th0, niter=1)              # reference reads lik[1]
     with pytest.raises(Exception):
-        eng.em_batch(y, np.zeros((9, 50)), v, synth.make_init_packed(9, 2, 2))   # p > 8
+        eng.em_batch(y, np.zeros((17, 50)), v, synth.make_init_packed(17, 2, 2))   # p > 16
 
 
 # ---- full BASELINE sizes: size-independent properties + sampled oracle parity -----------------
