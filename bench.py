@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan")
     ap.add_argument("--mask", default="dense", choices=["dense", "paleo"])
+    ap.add_argument("--niter", type=int, default=None, help="EM iteration cap (default: the workload's 100)")
+    ap.add_argument("--tol", type=float, default=0.0,
+                    help="stop tolerance; > 0 lets cells converge at their own pace and the "
+                         "units are the iterations actually executed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -179,7 +183,7 @@ def main():
     L = _lib.lib()
 
     w = WORKLOADS[args.workload]
-    T, p, q, niter = w["T"], w["p"], w["q"], w["niter"]
+    T, p, q, niter = w["T"], w["p"], w["q"], (args.niter or w["niter"])
     P = 6 + p + q
     Y, U, V, shared_uv, loc_off, th0, n_global = build_problem(args.workload, args.mask, world, rank)
     S_loc = Y.shape[0]
@@ -203,7 +207,7 @@ def main():
     def step():
         _lib.check(L.ldsr_em_batch_device(
             local_rank, C.c_void_p(stream.cuda_stream), S_loc, T, p, q, d_y.data_ptr(),
-            d_u.data_ptr(), d_v.data_ptr(), shared_uv, off, d_th0.data_ptr(), niter, 0.0, args.algo,
+            d_u.data_ptr(), d_v.data_ptr(), shared_uv, off, d_th0.data_ptr(), niter, args.tol, args.algo,
             d_th.data_ptr(), d_lik.data_ptr(), d_nit.data_ptr(), d_st.data_ptr(), None,
             C.c_void_p(ws_ptr), wsb))
 
@@ -230,20 +234,27 @@ def main():
     # the run must have done the work it claims
     nit = d_nit.cpu().numpy()
     st = d_st.cpu().numpy()
-    assert np.all(nit == niter), "cells stopped early"
+    if args.tol == 0.0:
+        assert np.all(nit == niter), "cells stopped early"
     assert np.all(st == 0), "non-finite likelihoods in the bench batch"
+    units_rank = int(nit.sum())            # E-steps actually executed by this rank per step
 
+    units_all = units_rank
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tdev = dev if backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        usum = torch.tensor([units_rank], dtype=torch.int64, device=tdev)
+        dist.all_reduce(usum, op=dist.ReduceOp.SUM)
+        units_all = int(usum.item())
 
     if rank == 0:
-        units_per_step = n_global * niter
+        units_per_step = units_all        # = n_global * niter when tol == 0
         value = units_per_step * args.steps / dt
         kern_ms = tot_ms.value / max(n_l.value, 1)
         bpu = bytes_per_unit(T, p, q)
-        alg_bytes = bpu * cells * niter                       # per launch (one GPU)
+        alg_bytes = bpu * units_rank                          # per launch (this GPU)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
@@ -256,7 +267,7 @@ def main():
                                    % (args.workload, T, p, q, w["series"], w["restarts"],
                                       "/GPU" if w["scaling"] == "weak" else " in total", niter,
                                       args.mask if w["series"] == 1 else "paleo-style"),
-                       "cells_rank0": cells, "cells_total": n_global, "niter": niter,
+                       "cells_rank0": cells, "cells_total": n_global, "niter": niter, "tol": args.tol,
                        "algo": args.algo, "units_per_step": units_per_step,
                        "sharding": "contiguous cell ranges over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -265,7 +276,7 @@ def main():
                          "valu_busy_frac": load_pmc(args.workload, "valu_busy_frac"),
                          "kernel": "em_scan_kernel" if args.algo != 1 else "em_serial_kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_unit": bpu,
-                         "units_per_launch": cells * niter,
+                         "units_per_launch": units_rank,
                          "note": "algorithmic (logical) traffic; the series is served from LDS "
                                  "and the filtered states never leave registers, so measured "
                                  "HBM traffic (traffic, bytes per launch, PMC) is far below it; "
