@@ -149,7 +149,10 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                                              const double *us, const double *vs, int s, int cell,
                                              int lane, int nl, int rp);
 
-template <int PP, int QQ, int L>
+// QUEUE = waves pull cells from the per-series work queue (cells converge at different
+// iterations); !QUEUE = wave w of block b owns cell c0 + w (every cell runs exactly niter
+// iterations, i.e. tol == 0: nothing to balance, and the queue loop costs ~6 % in spill code).
+template <int PP, int QQ, int L, bool QUEUE>
 __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
     // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
@@ -159,10 +162,9 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
 
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
-    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];   // QUEUE: the series' cells; else the block's
     const int T = prm.T;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int nl = (T + L - 1) / L;          // active lanes
     const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
     {
@@ -189,12 +191,31 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
         }
     }
     __syncthreads();
-    if (wave >= nc) return;   // whole wave leaves; no barrier follows
-    const int cell = c0 + wave;
-    if (prm.sc[s].n_obs == T)
-        em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, cell, lane, nl, rp);
-    else
-        em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, cell, lane, nl, rp);
+    const bool dense = prm.sc[s].n_obs == T;
+    if constexpr (!QUEUE) {
+        const int wave = threadIdx.x >> 6;
+        if (wave >= nc) return;   // whole wave leaves; no barrier follows
+        if (dense)
+            em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+        else
+            em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+    } else {
+        // Work queue: every wave pulls cells of this series until the counter passes the
+        // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
+        // instead of idling, which keeps two waves per SIMD busy when iteration counts differ a
+        // lot.  The counter only grows and the loop is bounded, so every wave reaches the exit;
+        // which wave computes a cell does not change its result.
+        for (int pulls = 0; pulls <= nc; pulls++) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(prm.queue + s, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= nc) break;
+            if (dense)
+                em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+            else
+                em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+        }
+    }
 }
 
 template <int PP, int QQ, int L, bool DENSE>
@@ -597,5 +618,5 @@ static inline int scan_wpb(int L, int PP, int QQ) {
 }
 
 template <int L>
-hipError_t launch_em_scan_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb,
+hipError_t launch_em_scan_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,
                             hipStream_t stream);

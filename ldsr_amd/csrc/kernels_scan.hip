@@ -19,18 +19,18 @@ bool em_scan_supported(int T, int PP, int QQ) {
 
 int em_scan_waves_per_block(int T, int PP, int QQ) { return scan_wpb(scan_L_for(T), PP, QQ); }
 
-hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb,
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb, bool queue,
                           hipStream_t stream) {
     switch (scan_L_for(prm.T)) {
-        case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 3: return launch_em_scan_L<3>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 6: return launch_em_scan_L<6>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 8: return launch_em_scan_L<8>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 12: return launch_em_scan_L<12>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 24: return launch_em_scan_L<24>(prm, PP, QQ, n_blocks, wpb, stream);
-        case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, stream);
+        case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 3: return launch_em_scan_L<3>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 6: return launch_em_scan_L<6>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 8: return launch_em_scan_L<8>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 12: return launch_em_scan_L<12>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 24: return launch_em_scan_L<24>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     __shared__ SeriesConst sc;
     __shared__ double inv_ws[LDSR_MAXPQ * LDSR_MAXPQ];
 
+    if (tid == 0 && prm.queue) prm.queue[s] = 0;
     // prepared copies
     for (int t = tid; t < T; t += 256) yp[t] = y[t];
     if (own_uv) {

@@ -98,7 +98,7 @@ static int cells_per_block(int algo, int T, int PP, int QQ) {
 }
 
 struct WsLayout {
-    size_t sc, yp, up, vp, blk, soc, scratch, total;
+    size_t sc, yp, up, vp, blk, soc, queue, scratch, total;
     long scratch_stride;
     int max_blocks;
 };
@@ -115,6 +115,7 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
+    L.queue = o; o = align256(o + sizeof(int) * (size_t)n_series);
     L.scratch_stride = ((long)n_cells + 63) / 64 * 64;
     L.scratch = o;
     if (algo == LDSR_ALGO_SERIAL) o = align256(o + sizeof(double) * 2 * (size_t)T * L.scratch_stride);
@@ -159,6 +160,7 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.up = (double *)(ws + L.up);
     pp.vp = (double *)(ws + L.vp);
     pp.sc = (SeriesConst *)(ws + L.sc);
+    pp.queue = (int *)(ws + L.queue);
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -194,15 +196,25 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     rc = prepare_series(stream, n_series, T, p, q, PP, QQ, d_y, d_u, d_v, shared_uv, ws, L);
     if (rc) return rc;
 
-    // block table: blocks never straddle a series
+    // block table: blocks never straddle a series.  Static mapping (serial kernel; scan kernel
+    // when tol == 0, i.e. every cell runs exactly niter iterations): (series, first cell, n cells
+    // of the block).  Work queue (scan kernel, tol > 0): (series, first cell of the SERIES, n
+    // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
+    // converges early takes the next one instead of idling.
+    const bool use_queue = algo == LDSR_ALGO_SCAN && tol > 0.0;
     std::vector<int> tab;
     tab.reserve(3 * (size_t)L.max_blocks);
     std::vector<int> bs, bc, bn;
     for (int s = 0; s < n_series; s++)
         for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
             bs.push_back(s);
-            bc.push_back(c);
-            bn.push_back(std::min(cpb, cell_offsets[s + 1] - c));
+            if (use_queue) {
+                bc.push_back(cell_offsets[s]);
+                bn.push_back(cell_offsets[s + 1] - cell_offsets[s]);
+            } else {
+                bc.push_back(c);
+                bn.push_back(std::min(cpb, cell_offsets[s + 1] - c));
+            }
         }
     const int n_blocks = (int)bs.size();
     if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow");
@@ -227,11 +239,12 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     prm.theta0 = d_theta0;
     prm.theta = d_theta; prm.lik = d_lik; prm.liks = d_liks;
     prm.n_iter = d_n_iter; prm.status = d_status;
+    prm.queue = (int *)(ws + L.queue);
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
     HIPCHK(prof_mark(stream, false));
     if (algo == LDSR_ALGO_SCAN)
-        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, cpb, stream));
+        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, cpb, use_queue, stream));
     else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
     HIPCHK(prof_mark(stream, true));

@@ -166,6 +166,7 @@ struct EmParams {
     long u_stride, v_stride; // doubles per series (0 when shared)
     const SeriesConst *sc;   // [n_series]
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
+    int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
     const double *theta0;    // [n_cells][6+p+q]
     double *theta, *lik, *liks;
     int *n_iter, *status;

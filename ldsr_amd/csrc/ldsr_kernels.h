@@ -9,6 +9,7 @@ struct PrepParams {
     const double *y, *u, *v;  // raw inputs as handed over the ABI (u / v may be null)
     double *yp, *up, *vp;     // prepared copies in the workspace
     SeriesConst *sc;
+    int *queue;               // [n_series] work-queue heads, reset to 0 here
 };
 
 struct SmoothParams {
@@ -30,7 +31,7 @@ static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream);
 hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);
 hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int waves_per_block,
-                          hipStream_t stream);
+                          bool queue, hipStream_t stream);
 bool em_scan_supported(int T, int PP, int QQ);
 int em_scan_waves_per_block(int T, int PP, int QQ);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);
