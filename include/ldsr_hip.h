@@ -91,7 +91,9 @@ int ldsr_em_batch_multi(int n_devices, const int *devices, int n_series, int T, 
 
 /* Same with DEVICE pointers (cell_offsets stays a host array).  Asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = default stream).  workspace: device buffer of at
- * least ldsr_em_workspace_bytes(...) bytes, 256-byte aligned. */
+ * least ldsr_em_workspace_bytes(...) bytes, 256-byte aligned; it holds the prepared series,
+ * the block table and the work-queue heads of THIS call, so calls that may overlap in time
+ * (different streams) need separate workspaces. */
 size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int n_cells, int algo);
 int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, int q,
                          const double *d_y, const double *d_u, const double *d_v,

@@ -544,3 +544,33 @@ def test_degenerate_initial_thetas_do_not_trap(eng, O, algo):
         if np.isfinite(ref[1][c]) and np.all(np.isfinite(ref[0][c])):
             assert r["n_iter"][c] == ref[2][c], c
             assert parity_close(r["lik"][c], ref[1][c], 1e-6, 1e-9), c
+
+
+def test_plain_c_client_links_the_abi(eng, O, p1case, tmp_path):
+    """The drop-in boundary is a C ABI: a gcc-built client with no HIP / Python dependency links
+    libldsr_hip.so, runs the reference's known-answer case plus random restarts through
+    ldsr_em_batch_multi + ldsr_select_restart, and must print what the oracle computes."""
+    import subprocess
+    from ldsr_amd import _lib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "client")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_client", "client.c"), "-o", exe,
+                           "-L", os.path.dirname(_lib.SO_PATH), "-lldsr_hip", "-lm",
+                           "-Wl,-rpath," + os.path.dirname(_lib.SO_PATH)])
+    c = p1case
+    th0 = synth.make_init_packed(7, 7, 12, seed=3)
+    th0[0] = c["theta0"]
+    case = tmp_path / "case.txt"
+    with open(case, "w") as f:
+        f.write("85 7 7 12 100 1e-5\n")
+        for arr in (c["y"], c["u"].T.ravel(), c["v"].T.ravel(), th0.ravel()):
+            f.write(" ".join(repr(float(x)) for x in arr) + "\n")
+    out = subprocess.check_output([exe, str(case)], text=True).split("\n")
+    k, nit, lik = out[0].split()
+    theta = np.array([float(x) for x in out[1].split()])
+    ref = _oracle_batch(O, c["y"], c["u"], c["v"], th0, 100, 1e-5)
+    kref = O.select(ref[1], ref[0][:, 8])
+    assert int(k) == kref and int(nit) == ref[2][kref]
+    assert parity_close(float(lik), ref[1][kref], RTOL, ATOL)
+    assert parity_close(theta, ref[0][kref], RTOL, ATOL)
