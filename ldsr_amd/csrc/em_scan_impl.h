@@ -263,7 +263,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     // wave per SIMD, so for them only the second half [HS, L) is kept; the reverse composite is
     // accumulated during the forward sweep and the first half's forward recursion is re-run
     // just before its backward sweep (+~20 % flops, twice the occupancy).
-    constexpr int HS = (L > 16) ? L / 2 : 0;
+    constexpr int HS = (L > 16) ? L / 2 : 0;   // L in {20, 24, 28, 32}
     constexpr int NS = L - HS;
     double Jv[NS], gv_[NS], hv[NS];
 

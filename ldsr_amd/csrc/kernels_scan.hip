@@ -5,7 +5,7 @@
 
 // smallest compiled chunk length with T <= 64*L; every choice also satisfies L*(L-1) <= T
 static int scan_L_for(int T) {
-    static const int Ls[] = {2, 3, 4, 6, 8, 12, 16, 24, 32};
+    static const int Ls[] = {2, 3, 4, 6, 8, 10, 12, 13, 14, 15, 16, 20, 24, 28, 32};
     for (int L : Ls)
         if (T <= 64 * L) return (T >= L * (L - 1)) ? L : 0;
     return 0;
@@ -27,9 +27,15 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int
         case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 6: return launch_em_scan_L<6>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 8: return launch_em_scan_L<8>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 10: return launch_em_scan_L<10>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 12: return launch_em_scan_L<12>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 13: return launch_em_scan_L<13>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 14: return launch_em_scan_L<14>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 15: return launch_em_scan_L<15>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 20: return launch_em_scan_L<20>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 24: return launch_em_scan_L<24>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+        case 28: return launch_em_scan_L<28>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         default: return hipErrorInvalidValue;
     }

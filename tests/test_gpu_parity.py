@@ -229,10 +229,12 @@ def test_tiny_series_fixed_iterations(eng, O, algo, T, p, q):
     _assert_batch_parity(r, ref, "tiny T=%d" % T)
 
 
-@pytest.mark.parametrize("T", [128, 129, 192, 193, 256, 384, 385, 512, 513, 768, 769, 1024, 1536, 1537, 2048])
+@pytest.mark.parametrize("T", [128, 129, 192, 193, 256, 384, 385, 512, 513, 640, 641, 768, 769, 813, 832, 833,
+                               896, 897, 960, 961, 1024, 1025, 1280, 1281, 1536, 1537, 1792, 1793, 2048])
 def test_scan_chunk_length_boundaries(eng, O, T):
-    """The scan kernel picks its chunk length L (2..32 steps per lane) from T; exercise both
-    sides of every switch point, with a ragged NA mask so the general (non-dense) path runs."""
+    """The scan kernel picks its chunk length L (2, 3, 4, 6, 8, 10, 12..16, 20, 24, 28, 32 steps
+    per lane) from T; exercise both sides of every switch point, with a ragged NA mask so the
+    general (non-dense) path runs."""
     from ldsr_amd import synth
     y, u, v = synth.make_series(T, 1, 2, series_id=T)
     y[T // 3:T // 3 + 5] = np.nan
