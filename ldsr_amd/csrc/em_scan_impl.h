@@ -1,10 +1,11 @@
-// em_scan_impl.h -- wave-per-cell, parallel-in-time EM kernel (the fast path, T <= 64*32).
+// em_scan_impl.h -- wave-per-cell, parallel-in-time EM kernel (the fast path: T <= 2048, p, q <= 8).
 //
-// One 64-lane wavefront owns one (series, restart) cell for the whole EM loop.  Lane l owns
-// the L consecutive time steps [l*L, l*L+L); all per-step state lives in that lane's
-// registers and nothing but the final theta ever goes to HBM.  The series (y,u,v) is staged
-// once per workgroup into LDS in a chunk-transposed layout [j][lane] so that the 64 lanes of
-// a wave read consecutive 8-byte words (conflict-free ds_read_b64).
+// One 64-lane wavefront owns one (series, restart) cell for the whole EM loop.  nl = ceil(T/L)
+// lanes are active; lane l owns L (the first rp lanes) or L-1 consecutive time steps, so only
+// the last step of a chunk is predicated.  All per-step state lives in that lane's registers
+// and nothing but the final theta / lik / n_iter / status ever goes to HBM.  The series
+// (y, u, v) is staged once per workgroup into LDS in a chunk-transposed layout [j][lane] so
+// that the 64 lanes of a wave read consecutive 8-byte words (conflict-free ds_read_b64).
 //
 // The reference recursions (/root/reference/src/EM.cpp:70-104) are strictly sequential in t.
 // They are compositions of associative maps, so each E-step is done in three phases per
@@ -17,17 +18,23 @@
 //                         xt' = ((A c/R) e + bu c^2/R) n + bu d + A xt
 //                     (the matrix of the filter step divided by R: projective coordinates
 //                     are scale free) with c = C on observed steps and 0 on missing ones,
-//                     e = y - D v, bu = B u.  (F1) every lane multiplies its L step matrices;
-//                     (scan) a 64-lane inclusive scan composes them; (F2) every lane re-runs
-//                     its L steps serially from its exact entry state with the reference's
-//                     own expressions and keeps J_t, g_t = Xu_t - J_t Xp_{t+1},
-//                     h_t = Vu_t - J_t^2 Vp_{t+1} in registers.
+//                     e = y - D v, bu = B u.  (F1) every lane multiplies its step matrices;
+//                     (scan) a 64-lane Kogge-Stone scan done with DPP row shifts / broadcasts
+//                     composes them; (F2) every lane re-runs its steps serially from its exact
+//                     entry state with the reference's own expressions and keeps J_t,
+//                     g_t = Xu_t - J_t Xp_{t+1}, h_t = Vu_t - J_t^2 Vp_{t+1} in registers.
 //  backward (:94-104) Xs_t = J_t Xs_{t+1} + g_t, Vs_t = J_t^2 Vs_{t+1} + h_t are affine maps:
-//                     (B1) compose per lane, (scan) reverse 64-lane scan, (B2) serial re-run
-//                     from the exact entry value, fused with every M-step sum (:151-193).
+//                     (B1) compose per lane, (scan) reverse scan by DPP + three readlanes,
+//                     (B2) serial re-run from the exact entry value, then all M-step sums
+//                     (:151-193) in an independent pass.
+//  then ONE wave all-reduce of every sum (M-step and likelihood), the stop rule (:272) and the
+//  closed-form M-step (ldsr_device.h) redundantly in every lane.
 //
-// Reassociation changes results at the 1e-15 level (measured against the oracle in
-// tests/test_gpu_parity.py); iteration counts are identical.
+// Chunks longer than 16 steps keep J/g/h for their second half only and re-run the first half's
+// forward recursion before its backward sweep (register budget: two waves per SIMD).
+//
+// Reassociation changes results at the 1e-12 level or below (measured against the oracle:
+// tools/parity_report.py); iteration counts are identical.
 #pragma once
 #include "ldsr_device.h"
 
