@@ -576,3 +576,18 @@ def test_plain_c_client_links_the_abi(eng, O, p1case, tmp_path):
     assert int(k) == kref and int(nit) == ref[2][kref]
     assert parity_close(float(lik), ref[1][kref], RTOL, ATOL)
     assert parity_close(theta, ref[0][kref], RTOL, ATOL)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("niter", [2, 3, 4])
+def test_smallest_iteration_caps(eng, O, p1case, algo, niter):
+    """niter = 2 is the least the reference can run (E, M, E; the loop of src/EM.cpp:259 never
+    executes): liks has niter entries and theta is the one that produced the last fit."""
+    c = p1case
+    fit = eng.LDS_EM(c["y"], c["u"], c["v"], c["theta0"], niter, 1e-5, algo=algo)
+    ref = O.lds_em(c["y"], c["u"], c["v"], c["theta0"], niter, 1e-5)
+    assert len(fit["liks"]) == len(ref["liks"]) == niter
+    assert parity_close(fit["liks"], ref["liks"], RTOL, ATOL)
+    assert parity_close(eng.pack_theta(fit["theta"], 7, 7), ref["theta"], RTOL, ATOL)
+    for k in "XYVJ":
+        assert parity_close(fit["fit"][k][0], ref["fit"][k], RTOL, ATOL), k
