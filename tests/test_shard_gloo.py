@@ -102,3 +102,43 @@ def test_rank_slices_cover_grid_exactly():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
     keep, loc = shard.local_offsets([0, 5, 5, 9, 12], 3, 10)
     assert keep.tolist() == [0, 2, 3] and loc.tolist() == [0, 2, 6, 7]
+
+
+def _gpu_worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")     # both ranks share the box's one GPU
+    import torch.distributed as dist
+
+    from ldsr_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Y, U, V, th0, off, p, q = _problem()
+        r = shard.em_batch_sharded(Y, U, V, th0, cell_offsets=off, niter=40, tol=1e-5)
+        q_out.put((rank, r))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_compute_on_the_gpu():
+    """Same as above with the real engine: two gloo ranks, each runs its slice through
+    ldsr_em_batch on the GPU; both must end with the single-process GPU result, bit for bit."""
+    import torch.multiprocessing as mp
+
+    import ldsr_amd
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    got = dict(q_out.get(timeout=180) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    Y, U, V, th0, off, p, q = _problem()
+    one = ldsr_amd.em_batch(Y, U, V, th0, cell_offsets=off, niter=40, tol=1e-5)
+    for rank in (0, 1):
+        for k in ("theta", "lik", "n_iter", "status"):
+            assert np.array_equal(got[rank][k], one[k], equal_nan=True), (rank, k)
