@@ -119,6 +119,32 @@ def host_cores():
     return n
 
 
+def rscript_reference_probe(T, p, q, niter):
+    """if (and only if) Rscript with the ldsr package is installed on this
+    box, time the real RcppArmadillo path (LDS_EM on one restart) and report it separately.
+    Never assumed: the build image and the GPU boxes seen so far have no R."""
+    import shutil
+    import subprocess
+    rs = shutil.which("Rscript")
+    if not rs:
+        return {"available": False, "why": "Rscript not found on PATH"}
+    code = ("suppressMessages(library(ldsr)); set.seed(1); T <- %d; p <- %d; q <- %d;"
+            "u <- matrix(rnorm(p*T), p, T); v <- matrix(rnorm(q*T), q, T); y <- matrix(rnorm(T), 1, T);"
+            "th <- make_init(p, q, 1)[[1]]; t0 <- proc.time()[3];"
+            "for (i in 1:8) r <- ldsr:::LDS_EM(y, u, v, th, %d, 0); cat(8 * %d / (proc.time()[3] - t0))"
+            % (T, p, q, niter, niter))
+    try:
+        out = subprocess.run([rs, "-e", code], capture_output=True, text=True, timeout=120)
+        if out.returncode != 0:
+            return {"available": False, "why": "Rscript present but ldsr not usable: "
+                    + out.stderr.strip().splitlines()[-1][:120] if out.stderr.strip() else "error"}
+        return {"available": True, "value": float(out.stdout.strip().split()[-1]),
+                "unit": "restart*EM-iter/s", "cores": 1, "kind": "reference",
+                "sample": "8 x LDS_EM(niter=%d, tol=0) on one R process" % niter}
+    except Exception as e:   # noqa: BLE001 -- a probe must never break the benchmark
+        return {"available": False, "why": "probe failed: %s" % type(e).__name__}
+
+
 def cpu_baseline(p, q, niter, Y, U, V, seed):
     """The CPU oracle on the first series of the workload (Y [S,T], U [.,T,p], V [.,T,q])."""
     from oracle import oracle as O
@@ -284,6 +310,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)
+            out["cpu_baseline"]["rscript_reference"] = rscript_reference_probe(T, p, q, niter)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
