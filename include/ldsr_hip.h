@@ -65,7 +65,8 @@ extern "C" {
 /* algorithm selector */
 #define LDSR_ALGO_AUTO 0
 #define LDSR_ALGO_SERIAL 1 /* one thread per cell, sequential in time (any T) */
-#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 2048, p, q <= 8) */
+#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 2048, p, q <= 8);
+                              AUTO picks it whenever it applies */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);

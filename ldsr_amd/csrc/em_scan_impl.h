@@ -151,7 +151,9 @@ __device__ __forceinline__ PMat pdpp(const PMat &m) {
 
 
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
-template <int PP, int QQ, int L, bool DENSE>
+// GIMG = the series is read from the prepared time-major arrays in global memory (ys/us/vs are
+// then this lane's own row pointers) instead of the chunk-transposed LDS image.
+template <int PP, int QQ, int L, bool DENSE, bool GIMG>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
                                              const double *us, const double *vs, int s, int cell,
                                              int lane, int nl, int rp);
@@ -159,13 +161,11 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 // QUEUE = waves pull cells from the per-series work queue (cells converge at different
 // iterations); !QUEUE = wave w of block b owns cell c0 + w (every cell runs exactly niter
 // iterations, i.e. tol == 0: nothing to balance, and the queue loop costs ~6 % in spill code).
-template <int PP, int QQ, int L, bool QUEUE>
+template <int PP, int QQ, int L, bool QUEUE, bool GIMG>
 __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
     // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
-    double *ys = smem;                  // [L][64]       y, 0 where missing / unused
-    double *us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t = T-1
-    double *vs = us + 64 * L * PP;      // [L][QQ][64]   v_t
+    double *ys, *us, *vs;
 
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
@@ -174,7 +174,17 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
     const int lane = threadIdx.x & 63;
     const int nl = (T + L - 1) / L;          // active lanes
     const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
-    {
+    if constexpr (GIMG) {
+        // no LDS image: every lane reads its own rows of the prepared arrays (clamped for the
+        // idle lanes, which never use them)
+        const int t0 = min(lane, nl - 1) * (L - 1) + min(min(lane, nl - 1), rp);
+        ys = const_cast<double *>(prm.yz) + (long)s * T + t0;
+        us = const_cast<double *>(prm.up) + (long)s * prm.u_stride + (long)t0 * PP;
+        vs = const_cast<double *>(prm.vp) + (long)s * prm.v_stride + (long)t0 * QQ;
+    } else {
+        ys = smem;                  // [L][64]       y, 0 where missing / unused
+        us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t = T-1
+        vs = us + 64 * L * PP;      // [L][QQ][64]   v_t
         const double *gy = prm.yp + (long)s * T;
         const double *gu = prm.up + (long)s * prm.u_stride;
         const double *gv = prm.vp + (long)s * prm.v_stride;
@@ -197,15 +207,15 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
             vs[i] = ok ? gv[(long)t * QQ + k] : 0.0;
         }
     }
-    __syncthreads();
+    if constexpr (!GIMG) __syncthreads();
     const bool dense = prm.sc[s].n_obs == T;
     if constexpr (!QUEUE) {
         const int wave = threadIdx.x >> 6;
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
         if (dense)
-            em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+            em_scan_cell<PP, QQ, L, true, GIMG>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
         else
-            em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+            em_scan_cell<PP, QQ, L, false, GIMG>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
     } else {
         // Work queue: every wave pulls cells of this series until the counter passes the
         // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
@@ -218,17 +228,21 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
             if (dense)
-                em_scan_cell<PP, QQ, L, true>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+                em_scan_cell<PP, QQ, L, true, GIMG>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
             else
-                em_scan_cell<PP, QQ, L, false>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+                em_scan_cell<PP, QQ, L, false, GIMG>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
         }
     }
 }
 
-template <int PP, int QQ, int L, bool DENSE>
+template <int PP, int QQ, int L, bool DENSE, bool GIMG>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
                                              const double *us, const double *vs, int s, int cell,
                                              int lane, int nl, int rp) {
+    // element (step j, row k) of this lane's chunk of y / u / v
+    auto Yat = [&](int j) { return GIMG ? ys[j] : ys[j * 64 + lane]; };
+    auto Uat = [&](int j, int k) { return GIMG ? us[j * PP + k] : us[(j * PP + k) * 64 + lane]; };
+    auto Vat = [&](int j, int k) { return GIMG ? vs[j * QQ + k] : vs[(j * QQ + k) * 64 + lane]; };
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
@@ -282,15 +296,15 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
         // e_t = y_t - D v_t (innovation minus C Xp) and bu_t = B u_t of step j of this lane, from LDS
         auto e_at = [&](int j) {
-            double e = ys[j * 64 + lane];
+            double e = Yat(j);
 #pragma unroll
-            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vs[(j * QQ + k) * 64 + lane], e);
+            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], Vat(j, k), e);
             return e;
         };
         auto bu_at = [&](int j) {
             double bu = 0.0;
 #pragma unroll
-            for (int k = 0; k < PP; k++) bu = fma(th.B[k], us[(j * PP + k) * 64 + lane], bu);
+            for (int k = 0; k < PP; k++) bu = fma(th.B[k], Uat(j, k), bu);
             return bu;
         };
 
@@ -494,17 +508,17 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             aTx1x = fma(Xnx, Xs, fma(Vnx, J, aTx1x));   // :180  (zero at t = T-1)
 #pragma unroll
             for (int k = 0; k < PP; k++) {
-                const double ut = us[(j * PP + k) * 64 + lane];   // zero at t = T-1
+                const double ut = Uat(j, k);                      // zero at t = T-1
                 aTx1u[k] = fma(Xnx, ut, aTx1u[k]);                // :190
                 aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
             }
             term = fma(Xs, Xs, Vs);
             aPall += term;                                        // :181,:183
             const double xo = o ? Xs : 0.0;
-            aSyx = fma(ys[j * 64 + lane], xo, aSyx);              // :151
+            aSyx = fma(Yat(j), xo, aSyx);                         // :151
             if (!DENSE) aSxx += o ? term : 0.0;                   // :152
 #pragma unroll
-            for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, vs[(j * QQ + k) * 64 + lane], aSxv[k]);  // :159
+            for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, Vat(j, k), aSxv[k]);  // :159
             if (L > 16 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {

@@ -11,16 +11,31 @@ static int scan_L_for(int T) {
     return 0;
 }
 
-bool em_scan_supported(int T, int PP, int QQ) {
-    const int L = scan_L_for(T);
-    if (!L || PP > 8 || QQ > 8) return false;   // instantiated for padded widths up to 8
+static bool lds_image_fits(int L, int PP, int QQ) {
     return (size_t)64 * L * (1 + PP + QQ) * sizeof(double) <= 160 * 1024;
 }
 
-int em_scan_waves_per_block(int T, int PP, int QQ) { return scan_wpb(scan_L_for(T), PP, QQ); }
+bool em_scan_supported(int T, int PP, int QQ) {
+    const int L = scan_L_for(T);
+    if (!L || PP > 8 || QQ > 8) return false;   // instantiated for padded widths up to 8
+    return lds_image_fits(L, PP, QQ) || L >= 20; // L >= 20 also exists in a global-image variant
+}
+
+// Long series with wide inputs: the chunk-transposed LDS image would exceed 160 KiB; the kernel
+// variant GIMG reads the prepared time-major arrays straight from global memory (L2 resident).
+bool em_scan_global_image(int T, int PP, int QQ) {
+    const int L = scan_L_for(T);
+    return L >= 20 && PP <= 8 && QQ <= 8 && !lds_image_fits(L, PP, QQ);
+}
+
+int em_scan_waves_per_block(int T, int PP, int QQ) {
+    if (em_scan_global_image(T, PP, QQ)) return 4;     // no LDS image: two workgroups per CU by VGPRs
+    return scan_wpb(scan_L_for(T), PP, QQ);
+}
 
 hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb, bool queue,
                           hipStream_t stream) {
+    if (em_scan_global_image(prm.T, PP, QQ)) queue = true;   // GIMG exists with the queue schedule only
     switch (scan_L_for(prm.T)) {
         case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, queue, stream);
         case 3: return launch_em_scan_L<3>(prm, PP, QQ, n_blocks, wpb, queue, stream);

@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
 
     if (tid == 0 && prm.queue) prm.queue[s] = 0;
     // prepared copies
-    for (int t = tid; t < T; t += 256) yp[t] = y[t];
+    for (int t = tid; t < T; t += 256) {
+        const double yv = y[t];
+        yp[t] = yv;
+        prm.yz[(long)s * T + t] = isfinite(yv) ? yv : 0.0;
+    }
     if (own_uv) {
         for (int i = tid; i < T * PP; i += 256) {
             const int t = i / PP, k = i - t * PP;

@@ -98,7 +98,7 @@ static int cells_per_block(int algo, int T, int PP, int QQ) {
 }
 
 struct WsLayout {
-    size_t sc, yp, up, vp, blk, soc, queue, scratch, total;
+    size_t sc, yp, yz, up, vp, blk, soc, queue, scratch, total;
     long scratch_stride;
     int max_blocks;
 };
@@ -109,6 +109,7 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     size_t o = 0;
     L.sc = o; o = align256(o + sizeof(SeriesConst) * (size_t)n_series);
     L.yp = o; o = align256(o + sizeof(double) * (size_t)n_series * T);
+    L.yz = o; o = align256(o + sizeof(double) * (size_t)n_series * T);
     const size_t nuv = shared_uv ? 1 : (size_t)n_series;
     L.up = o; o = align256(o + sizeof(double) * nuv * T * PP);
     L.vp = o; o = align256(o + sizeof(double) * nuv * T * QQ);
@@ -157,6 +158,7 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.T = T; pp.p = p; pp.q = q; pp.PP = PP; pp.QQ = QQ; pp.shared_uv = shared_uv;
     pp.y = d_y; pp.u = d_u; pp.v = d_v;
     pp.yp = (double *)(ws + L.yp);
+    pp.yz = (double *)(ws + L.yz);
     pp.up = (double *)(ws + L.up);
     pp.vp = (double *)(ws + L.vp);
     pp.sc = (SeriesConst *)(ws + L.sc);
@@ -183,7 +185,7 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN) return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
-        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 2048 and an LDS image of the series <= 160 KiB");
+        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 2048 and p, q <= 8");
     const int cpb = cells_per_block(algo, T, PP, QQ);
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo, cpb);
     if (workspace_bytes < L.total)
@@ -201,7 +203,7 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     // of the block).  Work queue (scan kernel, tol > 0): (series, first cell of the SERIES, n
     // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
     // converges early takes the next one instead of idling.
-    const bool use_queue = algo == LDSR_ALGO_SCAN && tol > 0.0;
+    const bool use_queue = algo == LDSR_ALGO_SCAN && (tol > 0.0 || em_scan_global_image(T, PP, QQ));
     std::vector<int> tab;
     tab.reserve(3 * (size_t)L.max_blocks);
     std::vector<int> bs, bc, bn;
@@ -228,6 +230,7 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     prm.T = T; prm.p = p; prm.q = q; prm.has_u = d_u != nullptr; prm.has_v = d_v != nullptr;
     prm.niter = niter; prm.n_cells = n_cells; prm.tol = tol;
     prm.yp = (const double *)(ws + L.yp);
+    prm.yz = (const double *)(ws + L.yz);
     prm.up = (const double *)(ws + L.up);
     prm.vp = (const double *)(ws + L.vp);
     prm.u_stride = shared_uv ? 0 : (long)T * PP;

@@ -161,6 +161,7 @@ struct EmParams {
     int T, p, q, has_u, has_v, niter, n_cells;
     double tol;
     const double *yp;        // [n_series][T]       NaN = missing
+    const double *yz;        // [n_series][T]       same with 0 where missing (scan kernel, global-image variant)
     const double *up;        // [n_series or 1][T][PP]  zero padded, row T-1 zeroed
     const double *vp;        // [n_series or 1][T][QQ]
     long u_stride, v_stride; // doubles per series (0 when shared)

@@ -8,6 +8,7 @@ struct PrepParams {
     int T, p, q, PP, QQ, shared_uv;
     const double *y, *u, *v;  // raw inputs as handed over the ABI (u / v may be null)
     double *yp, *up, *vp;     // prepared copies in the workspace
+    double *yz;               // y with 0 where missing
     SeriesConst *sc;
     int *queue;               // [n_series] work-queue heads, reset to 0 here
 };
@@ -32,6 +33,7 @@ hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t s
 hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);
 hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int waves_per_block,
                           bool queue, hipStream_t stream);
+bool em_scan_global_image(int T, int PP, int QQ);   // series image too large for LDS: read from L2
 bool em_scan_supported(int T, int PP, int QQ);
 int em_scan_waves_per_block(int T, int PP, int QQ);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);

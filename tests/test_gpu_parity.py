@@ -607,3 +607,19 @@ def test_large_batch_is_consistent_with_small_batches(eng):
             small = eng.em_batch(y, u, v, th0[lo:lo + 257], niter=niter, tol=tol)
             for k in ("theta", "lik", "n_iter"):
                 assert np.array_equal(small[k], big[k][lo:lo + 257]), (tol, lo, k)
+
+
+@pytest.mark.parametrize("T,p,q,mask", [(1700, 7, 5, "paleo"), (2048, 8, 8, "dense"), (1281, 4, 5, "dense"),
+                                        (1900, 2, 8, "paleo")])
+def test_long_wide_series_use_the_global_image_scan(eng, O, T, p, q, mask):
+    """T > 1024 with wide inputs: the chunk-transposed series image exceeds the 160 KiB LDS, so
+    the scan kernel reads the prepared arrays from global memory (GIMG variant).  Same parity
+    bar; LDSR_ALGO_SCAN must accept these shapes."""
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(T, p, q, series_id=T + p, mask=mask, n_tail=T // 3)
+    y[5:9] = np.nan
+    th0 = synth.make_init_packed(p, q, 10, seed=T)
+    for niter, tol in ((40, 1e-5), (12, 0.0)):
+        r = eng.em_batch(y, u, v, th0, niter=niter, tol=tol, algo=2)
+        ref = _oracle_batch(O, y, u, v, th0, niter, tol)
+        _assert_batch_parity(r, ref, "GIMG T=%d p=%d q=%d" % (T, p, q))
