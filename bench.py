@@ -8,19 +8,33 @@ so every cell runs exactly 100 E-steps) = 409 600 restart x EM-iteration units p
 Inputs (y, u, v, theta0) are resident in HBM before the timed region.  --workload selects the
 other BASELINE configs (cfg3 per GPU; cfg4 / cfg5 fixed grids) for DESIGN.md's table.
 
-N > 1 (launched by torch.distributed.run): restarts shard embarrassingly -- every rank runs
-its own 4096 restarts of the same series (restart index = global position in the counter-based
-generator), no data-path collective; "scaling": "weak" (cfg4 / cfg5: "strong").
+N > 1: one process per GPU.  `python bench.py --gpus N` invoked plainly starts the N ranks
+itself (a child `python -m torch.distributed.run`, before this process touches the GPU); under
+torch.distributed.run it is a rank.  Restarts shard embarrassingly -- contiguous cell ranges, no
+data-path collective (R/LDS_reconstruction.R:46 is a %dopar% over independent tasks).  The
+headline fields are WEAK scaling (every rank its own 4096 restarts; restart index = global
+position in the counter-based generator); for the single-series workloads the same run also
+times the STRONG split of BASELINE config 2 (4096 restarts / N per rank) and reports it in
+"strong_scaling".  cfg4 / cfg5 are fixed grids -> "strong" by construction.
 
 Prints ONE JSON line on rank 0; see the task contract for the fields.  Extra objects:
-  roofline      algorithmic bytes (16*T*(3+p+q) per unit) / EM-kernel time
-                measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+  roofline      the binding resource is fp64 VALU issue, not HBM: achieved = algorithmic flops
+                ((6p+6q+50)*T per unit) / EM-kernel time measured with HIP events
+                on the launch stream, against the 78.6 TFLOP/s fp64 vector peak.  The nominal HBM
+                figure of BASELINE.json (16*T*(3+p+q) logical bytes per unit) is
+                kept as hbm_logical_*: it is NOT traffic -- the series lives in LDS and the
+                filtered states in registers, so it can exceed the 8 TB/s peak.  Counter-measured
+                numbers (HBM bytes per launch, VALU instructions) come from committed rocprofv3
+                --pmc passes of this same command (profiles/pmc_summary.json) and are emitted
+                only when an entry for this workload AND this kernel instantiation exists.
   cpu_baseline  the CPU oracle (a port of src/EM.cpp, not RcppArmadillo) on the host cores
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,18 +56,23 @@ WORKLOADS = {
                  kind="stations"),     # 48 independent series, observed tail of 30..90 steps
 }
 
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2 flop x 2.4 GHz (AMD spec)
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
-def build_problem(name, mask, world, rank):
+
+def build_problem(name, mask, world, rank, scaling=None):
     """Host arrays of this rank's slice of the workload's (series, restart) grid:
     Y [S,T], U [S or 1,T,p], V [S or 1,T,q] (time-major), shared_uv, cell_offsets [S+1],
-    theta0 [cells, P], plus the global cell count."""
+    theta0 [cells, P], plus the global cell count.  scaling="strong" on a single-series
+    workload splits its `restarts` over the ranks instead of giving every rank that many."""
     from ldsr_amd import shard, synth
     w = WORKLOADS[name]
     T, p, q, S, R = w["T"], w["p"], w["q"], w["series"], w["restarts"]
     kind = w.get("kind", "single")
     if kind == "single":
         y, u, v = synth.make_series(T, p, q, series_id=0, mask=mask)
-        n_global = world * R                       # weak: R restarts per rank
+        n_global = R if scaling == "strong" else world * R   # weak: R restarts per rank
         lo, hi = shard.rank_slice(n_global, world, rank)
         th0 = synth.make_init_packed(p, q, hi - lo, seed=1, first=lo)
         return (y[None], np.ascontiguousarray(u.T[None]), np.ascontiguousarray(v.T[None]), 0,
@@ -84,23 +103,38 @@ def build_problem(name, mask, world, rank):
         U, V = np.ascontiguousarray(U[keep]), np.ascontiguousarray(V[keep])
     return Yk, U, V, shared, loc, th0, n_global
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-
 
 def bytes_per_unit(T, p, q):
+    """Logical bytes of one E+M unit: y, u, v read twice, (Xu, Vu) written+read."""
     return 16 * T * (3 + p + q)
 
 
-def load_pmc(workload, key):
-    """A value of the committed rocprofv3 --pmc summary (profiles/pmc_summary.json), or None.
+def flops_per_unit(T, p, q):
+    """Algorithmic fp64 flops of one E+M unit, divides and logs counted as 1."""
+    return (6 * p + 6 * q + 50) * T
+
+
+def load_pmc(workload, mask, kernel, niter, tol):
+    """The committed rocprofv3 --pmc summary for this workload (profiles/pmc_summary.json).
     PMC counters cannot be collected from inside the timed run; they come from separate
-    rocprofv3 passes of this same command and are committed under profiles/."""
+    rocprofv3 passes of this same command.  Returns (entry, stale): the entry recorded for this
+    workload, and whether it was measured on ANOTHER kernel instantiation / iteration setup than
+    the one being timed now (then its numbers describe an older build and are flagged)."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get(key)
+            entries = json.load(f).get("entries", [])
     except (OSError, ValueError):
-        return None
+        return None, None
+    best = None
+    for e in entries:
+        if e.get("workload") != workload or e.get("mask", "dense") != mask:
+            continue
+        exact = (e.get("kernel") == kernel and e.get("niter") == niter and e.get("tol") == tol)
+        if exact:
+            return e, False
+        best = best or e
+    return (best, True) if best else (None, None)
 
 
 def host_cores():
@@ -124,7 +158,6 @@ def rscript_reference_probe(T, p, q, niter):
     box, time the real RcppArmadillo path (LDS_EM on one restart) and report it separately.
     Never assumed: the build image and the GPU boxes seen so far have no R."""
     import shutil
-    import subprocess
     rs = shutil.which("Rscript")
     if not rs:
         return {"available": False, "why": "Rscript not found on PATH"}
@@ -145,26 +178,88 @@ def rscript_reference_probe(T, p, q, niter):
         return {"available": False, "why": "probe failed: %s" % type(e).__name__}
 
 
-def cpu_baseline(p, q, niter, Y, U, V, seed):
-    """The CPU oracle on the first series of the workload (Y [S,T], U [.,T,p], V [.,T,q])."""
+def cpu_baseline(p, q, niter, Y, U, V, seed, target_s=12.0):
+    """The CPU oracle on the first series of the workload (Y [S,T], U [.,T,p], V [.,T,q]):
+    a short pilot sizes a sample of about `target_s` seconds on every usable host core."""
     from oracle import oracle as O
-    cores = host_cores()
     from ldsr_amd import synth
-    cells = 512 * cores
-    th0 = synth.make_init_packed(p, q, cells, seed=seed)
+    cores = host_cores()
     Y = np.ascontiguousarray(Y[:1])
     U = np.ascontiguousarray(U[:1])
     V = np.ascontiguousarray(V[:1])
-    soc = np.zeros(cells, np.int32)
-    O.em_batch(Y, U, V, soc[:cores], th0[:cores], 3, 0.0, n_threads=cores)      # warm
+    pilot = 64 * cores
+    th0 = synth.make_init_packed(p, q, pilot, seed=seed)
+    O.em_batch(Y, U, V, np.zeros(cores, np.int32), th0[:cores], 3, 0.0, n_threads=cores)   # warm
     t0 = time.perf_counter()
-    O.em_batch(Y, U, V, soc, th0, niter, 0.0, n_threads=cores)
+    O.em_batch(Y, U, V, np.zeros(pilot, np.int32), th0, niter, 0.0, n_threads=cores)
+    rate = pilot * niter / (time.perf_counter() - t0)
+    cells = int(min(max(rate * target_s / niter, pilot), 1 << 18)) // cores * cores
+    th0 = synth.make_init_packed(p, q, cells, seed=seed)
+    t0 = time.perf_counter()
+    O.em_batch(Y, U, V, np.zeros(cells, np.int32), th0, niter, 0.0, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": cells * niter / dt, "unit": "restart*EM-iter/s", "cores": cores,
             "kind": "port",
             "sample": "%d restarts x %d EM iterations of the same series, %d host threads, %.1f s "
                       "(CPU oracle = scalar fp64 port of src/EM.cpp, not RcppArmadillo)"
                       % (cells, niter, cores, dt)}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` invoked plainly: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (this parent never imports torch or touches the GPU, and
+    nothing is exec'ed from a process that has), forward its output and exit with its code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+class Job:
+    """Device-resident operands of one rank's slice and the one-call step over them."""
+
+    def __init__(self, L, torch, dev, local_rank, prob, T, p, q, niter, tol, algo):
+        from ldsr_amd import _lib
+        Y, U, V, self.shared_uv, loc_off, th0, self.n_global = prob
+        self.S, self.cells = Y.shape[0], th0.shape[0]
+        self.d_y = torch.from_numpy(Y).to(dev)          # [S][T]
+        self.d_u = torch.from_numpy(U).to(dev)          # [S or 1][T][p]
+        self.d_v = torch.from_numpy(V).to(dev)          # [S or 1][T][q]
+        self.d_th0 = torch.from_numpy(th0).to(dev)
+        self.d_th = torch.empty_like(self.d_th0)
+        self.d_lik = torch.empty(self.cells, dtype=torch.float64, device=dev)
+        self.d_nit = torch.empty(self.cells, dtype=torch.int32, device=dev)
+        self.d_st = torch.empty(self.cells, dtype=torch.int32, device=dev)
+        self.wsb = L.ldsr_em_workspace_bytes(self.S, T, p, q, self.cells, algo)
+        assert self.wsb > 0
+        self.d_ws = torch.empty(self.wsb + 256, dtype=torch.uint8, device=dev)
+        ws_ptr = (self.d_ws.data_ptr() + 255) & ~255
+        off = (C.c_int * (self.S + 1))(*[int(x) for x in loc_off])
+        stream = torch.cuda.current_stream(dev)
+
+        def step():
+            _lib.check(L.ldsr_em_batch_device(
+                local_rank, C.c_void_p(stream.cuda_stream), self.S, T, p, q, self.d_y.data_ptr(),
+                self.d_u.data_ptr(), self.d_v.data_ptr(), self.shared_uv, off,
+                self.d_th0.data_ptr(), niter, tol, algo, self.d_th.data_ptr(),
+                self.d_lik.data_ptr(), self.d_nit.data_ptr(), self.d_st.data_ptr(), None,
+                C.c_void_p(ws_ptr), self.wsb))
+        self.step = step
+
+    def units(self, niter, tol):
+        """E-steps this rank executes per step, after checking the run did the work it claims."""
+        nit = self.d_nit.cpu().numpy()
+        st = self.d_st.cpu().numpy()
+        if tol == 0.0:
+            assert np.all(nit == niter), "cells stopped early"
+        assert np.all(st == 0), "non-finite likelihoods in the bench batch"
+        return int(nit.sum())
 
 
 def main():
@@ -179,8 +274,14 @@ def main():
     ap.add_argument("--tol", type=float, default=0.0,
                     help="stop tolerance; > 0 lets cells converge at their own pace and the "
                          "units are the iterations actually executed")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="headline split of a single-series workload over the ranks (default weak: "
+                         "the per-GPU configuration of BASELINE.json; strong: its restarts / N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -189,13 +290,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-    # Rehearsal on a one-GPU box: LDSR_BENCH_BACKEND=gloo LDSR_BENCH_ONE_GPU=1 lets several ranks
-    # share cuda:0 (the driver's real runs use one GPU per rank over RCCL).
-    backend = os.environ.get("LDSR_BENCH_BACKEND", "nccl")
-    if os.environ.get("LDSR_BENCH_ONE_GPU") == "1":
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # Rehearsal on a one-GPU box: LDSR_BENCH_ONE_GPU=1 lets several ranks share cuda:0 over gloo
+    # (the driver's real runs use one GPU per rank over RCCL).
+    one_gpu = os.environ.get("LDSR_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("LDSR_BENCH_BACKEND", "gloo" if one_gpu else "nccl")
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -205,37 +305,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from ldsr_amd import _lib, shard, synth
+    from ldsr_amd import _lib
     L = _lib.lib()
 
     w = WORKLOADS[args.workload]
     T, p, q, niter = w["T"], w["p"], w["q"], (args.niter or w["niter"])
-    P = 6 + p + q
-    Y, U, V, shared_uv, loc_off, th0, n_global = build_problem(args.workload, args.mask, world, rank)
-    S_loc = Y.shape[0]
-    cells = th0.shape[0]
-
-    d_y = torch.from_numpy(Y).to(dev)          # [S][T]
-    d_u = torch.from_numpy(U).to(dev)          # [S or 1][T][p]
-    d_v = torch.from_numpy(V).to(dev)          # [S or 1][T][q]
-    d_th0 = torch.from_numpy(th0).to(dev)
-    d_th = torch.empty_like(d_th0)
-    d_lik = torch.empty(cells, dtype=torch.float64, device=dev)
-    d_nit = torch.empty(cells, dtype=torch.int32, device=dev)
-    d_st = torch.empty(cells, dtype=torch.int32, device=dev)
-    wsb = L.ldsr_em_workspace_bytes(S_loc, T, p, q, cells, args.algo)
-    assert wsb > 0
-    d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
-    ws_ptr = (d_ws.data_ptr() + 255) & ~255
-    off = (C.c_int * (S_loc + 1))(*[int(x) for x in loc_off])
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        _lib.check(L.ldsr_em_batch_device(
-            local_rank, C.c_void_p(stream.cuda_stream), S_loc, T, p, q, d_y.data_ptr(),
-            d_u.data_ptr(), d_v.data_ptr(), shared_uv, off, d_th0.data_ptr(), niter, args.tol, args.algo,
-            d_th.data_ptr(), d_lik.data_ptr(), d_nit.data_ptr(), d_st.data_ptr(), None,
-            C.c_void_p(ws_ptr), wsb))
+    single = w["series"] == 1
+    scaling = (args.scaling or w["scaling"]) if single else w["scaling"]
+    job = Job(L, torch, dev, local_rank,
+              build_problem(args.workload, args.mask, world, rank, scaling), T, p, q, niter,
+              args.tol, args.algo)
+    name_buf = C.create_string_buffer(160)
+    algo_resolved = L.ldsr_em_plan(T, p, q, niter, args.tol, args.algo, name_buf, 160)
+    kernel_name = name_buf.value.decode()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -243,76 +325,108 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    L.ldsr_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tot_ms = C.c_double()
-    n_l = C.c_int()
-    _lib.check(L.ldsr_profile_collect(C.byref(tot_ms), C.byref(n_l)))
-    L.ldsr_profile_enable(0)
-
-    # the run must have done the work it claims
-    nit = d_nit.cpu().numpy()
-    st = d_st.cpu().numpy()
-    if args.tol == 0.0:
-        assert np.all(nit == niter), "cells stopped early"
-    assert np.all(st == 0), "non-finite likelihoods in the bench batch"
-    units_rank = int(nit.sum())            # E-steps actually executed by this rank per step
-
-    units_all = units_rank
-    if world > 1:
+    def reduce_over_ranks(dt, units_rank):
+        if world == 1:
+            return dt, units_rank
         tdev = dev if backend == "nccl" else "cpu"
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         usum = torch.tensor([units_rank], dtype=torch.int64, device=tdev)
         dist.all_reduce(usum, op=dist.ReduceOp.SUM)
-        units_all = int(usum.item())
+        return float(tmax.item()), int(usum.item())
+
+    def timed(j, profile):
+        """W warm-up steps, then exactly K steps between barrier + synchronize brackets."""
+        for _ in range(args.warmup):
+            j.step()
+        barrier()
+        if profile:
+            L.ldsr_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            j.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms = None
+        if profile:
+            tot_ms, n_l = C.c_double(), C.c_int()
+            _lib.check(L.ldsr_profile_collect(C.byref(tot_ms), C.byref(n_l)))
+            L.ldsr_profile_enable(0)
+            kern_ms = tot_ms.value / max(n_l.value, 1)
+        units_rank = j.units(niter, args.tol)
+        dt, units_all = reduce_over_ranks(dt, units_rank)
+        return dt, units_rank, units_all, kern_ms
+
+    dt, units_rank, units_all, kern_ms = timed(job, True)
+
+    strong = None
+    if world > 1 and single and scaling == "weak":
+        # the same run, BASELINE config 2 as ONE job split N ways (restarts / N per rank)
+        sjob = Job(L, torch, dev, local_rank,
+                   build_problem(args.workload, args.mask, world, rank, "strong"), T, p, q, niter,
+                   args.tol, args.algo)
+        sdt, _, sunits_all, _ = timed(sjob, False)
+        strong = {"scaling": "strong", "cells_total": sjob.n_global, "cells_rank0": sjob.cells,
+                  "value": sunits_all * args.steps / sdt, "unit": "restart*EM-iter/s",
+                  "ms_per_step": sdt / args.steps * 1e3, "units_per_step": sunits_all}
 
     if rank == 0:
-        units_per_step = units_all        # = n_global * niter when tol == 0
-        value = units_per_step * args.steps / dt
-        kern_ms = tot_ms.value / max(n_l.value, 1)
-        bpu = bytes_per_unit(T, p, q)
-        alg_bytes = bpu * units_rank                          # per launch (this GPU)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        value = units_all * args.steps / dt
+        kern_s = kern_ms * 1e-3
+        fpu, bpu = flops_per_unit(T, p, q), bytes_per_unit(T, p, q)
+        tflops = fpu * units_rank / kern_s / 1e12             # this GPU's kernel
+        logical_gbs = bpu * units_rank / kern_s / 1e9
+        pmc, stale = load_pmc(args.workload, args.mask, kernel_name, niter, args.tol)
+        roof = {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                "traffic": None, "kernel": kernel_name, "kernel_ms": kern_ms,
+                "algorithmic_flops_per_unit": fpu, "units_per_launch": units_rank,
+                "hbm_logical_bytes_per_unit": bpu, "hbm_logical_gbs": logical_gbs,
+                "hbm_logical_frac": logical_gbs / HBM_PEAK_GBS, "hbm_peak_gbs": HBM_PEAK_GBS,
+                "note": "fp64 VALU issue is the binding resource; hbm_logical_* is BASELINE.json's "
+                        "nominal byte figure (not traffic: the series is served from LDS, the "
+                        "filtered states never leave registers) and may exceed 1; traffic / "
+                        "hbm_measured_* / issue_frac are rocprofv3 PMC numbers of the committed "
+                        "passes named in pmc_source"}
+        if pmc is not None:
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["pmc_source"] = pmc.get("source")
+            roof["pmc_stale"] = bool(stale)
+            if pmc.get("hbm_bytes_per_launch") is not None:
+                roof["hbm_measured_gbs"] = pmc["hbm_bytes_per_launch"] / kern_s / 1e9
+                roof["hbm_measured_frac"] = roof["hbm_measured_gbs"] / HBM_PEAK_GBS
+            if pmc.get("valu_insts_per_unit") is not None:
+                # wave-instructions issued per second against 1024 SIMDs x one fp64 issue / 4 clk
+                roof["valu_insts_per_unit"] = pmc["valu_insts_per_unit"]
+                roof["issue_frac"] = (pmc["valu_insts_per_unit"] * units_rank / kern_s
+                                      / (N_SIMD * CLOCK_HZ / 4.0))
+            if pmc.get("valu_busy_frac") is not None:
+                roof["valu_busy_frac"] = pmc["valu_busy_frac"]
         out = {
             "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
             "value": value, "unit": "restart*EM-iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": w["scaling"], "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s: synthetic T=%d p=%d q=%d, %d series x %d restarts%s, "
-                                   "niter=%d, tol=0, %s mask"
+                                   "niter=%d, tol=%g, %s mask"
                                    % (args.workload, T, p, q, w["series"], w["restarts"],
-                                      "/GPU" if w["scaling"] == "weak" else " in total", niter,
-                                      args.mask if w["series"] == 1 else "paleo-style"),
-                       "cells_rank0": cells, "cells_total": n_global, "niter": niter, "tol": args.tol,
-                       "algo": args.algo, "units_per_step": units_per_step,
+                                      "/GPU" if scaling == "weak" else " in total", niter, args.tol,
+                                      args.mask if single else "paleo-style"),
+                       "cells_rank0": job.cells, "cells_total": job.n_global, "niter": niter,
+                       "tol": args.tol, "algo": algo_resolved, "units_per_step": units_all,
                        "sharding": "contiguous cell ranges over %d rank(s), no collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc(args.workload, "hbm_bytes_per_launch"),
-                         "valu_busy_frac": load_pmc(args.workload, "valu_busy_frac"),
-                         "kernel": "em_scan_kernel" if args.algo != 1 else "em_serial_kernel",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_unit": bpu,
-                         "units_per_launch": units_rank,
-                         "note": "algorithmic (logical) traffic; the series is served from LDS "
-                                 "and the filtered states never leave registers, so measured "
-                                 "HBM traffic (traffic, bytes per launch, PMC) is far below it; "
-                                 "the binding resource is fp64 VALU issue (valu_busy_frac, PMC)"},
+            "roofline": roof,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
+            Y, U, V = (job.d_y.cpu().numpy(), job.d_u.cpu().numpy(), job.d_v.cpu().numpy())
             out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)
             out["cpu_baseline"]["rscript_reference"] = rscript_reference_probe(T, p, q, niter)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

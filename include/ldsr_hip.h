@@ -4,7 +4,15 @@
  *
  * What each entry point replaces in the reference (paths under /root/reference):
  *
- *   ldsr_em_batch            the whole fan-out  foreach(theta0 = init) %dopar% LDS_EM(...)
+ *   ldsr_em_restart_grid     LDS_EM_restart (R/LDS_reconstruction.R:42-62) for one series, and
+ *                            the fold loop of cvLDS (R/LDS_reconstruction.R:373-375 ->
+ *                            one_lds_cv :270-285) for several: the foreach fan-out :46, the
+ *                            selection :50-58 and the winner's model {theta, fit, liks, lik} in
+ *                            ONE call -- only the winners' fit / liks cross PCIe
+ *   ldsr_em_restart_groups   the ensemble loop R/LDS_reconstruction.R:242-246 (members differ in
+ *                            p, q: tests/testthat/test-ensemble.R:4-5): one grid per member,
+ *                            run concurrently
+ *   ldsr_em_batch            the bare fan-out  foreach(theta0 = init) %dopar% LDS_EM(...)
  *                            of R/LDS_reconstruction.R:46, i.e. n_cells calls of
  *                            _ldsr_LDS_EM (src/RcppExports.cpp:40-53 -> src/EM.cpp:245-280),
  *                            batched over restarts and over series / CV folds
@@ -40,8 +48,13 @@
  * unconditionally, src/EM.cpp:256).
  *
  * Every function returns LDSR_OK (0) or an error code; ldsr_last_error() gives the
- * message of the calling thread's last failure.  Nothing is retained between calls except the
- * optional kernel-timer events, freed by ldsr_shutdown().
+ * message of the calling thread's last failure.
+ *
+ * Ownership: the library never keeps a pointer of the caller after a call returns.  The
+ * host-pointer entry points cache their device buffers, pinned staging buffers and one stream
+ * per concurrent caller and device (grow-only arenas; a call on a busy device gets its own), so
+ * repeated calls do no hipMalloc / hipFree; ldsr_shutdown() frees everything.  All entry
+ * points may be called from several threads.
  */
 #ifndef LDSR_HIP_H
 #define LDSR_HIP_H
@@ -65,13 +78,53 @@ extern "C" {
 /* algorithm selector */
 #define LDSR_ALGO_AUTO 0
 #define LDSR_ALGO_SERIAL 1 /* one thread per cell, sequential in time (any T) */
-#define LDSR_ALGO_SCAN 2   /* one wavefront per cell, parallel-in-time scans (T <= 2048, p, q <= 8);
-                              AUTO picks it whenever it applies */
+#define LDSR_ALGO_SCAN 2   /* one to four wavefronts per cell, parallel-in-time scans (T <= 8192,
+                              p, q <= 8); AUTO picks it whenever it applies */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);
 int ldsr_device_count(void);
 void ldsr_shutdown(void);
+
+/* LDS_EM_restart for a whole grid of series / CV folds in one call: runs every (series,
+ * restart) cell (cells are cut into contiguous slices over devices[0..n_devices), host threads,
+ * no collective), picks each series' winner by the reference's rule (highest lik among
+ * restarts with C > 0 if any, NaN ignored, first index on ties), and returns per series the
+ * winner's model exactly as LDS_EM returns it (src/EM.cpp:276-279):
+ *   winner   [n_series]          global cell index, or -1 if nothing is selectable
+ *   theta_w  [n_series][6+p+q]   lik_w [n_series]   n_iter_w [n_series]
+ *   liks_w   [n_series][niter]   the winner's likelihood trace, NaN beyond n_iter_w[s]
+ *   X, Y, V, J [n_series][T]     the winner's fit (Kalman_smoother at theta_w, stdlik = TRUE)
+ * Rows of a series without a winner are NaN.  liks_w, X, Y, V, J may each be NULL.
+ * The per-cell results (theta_all [n_cells][6+p+q], lik_all, n_iter_all, status_all) are
+ * optional: pass NULL to leave them on the device side of PCIe. */
+int ldsr_em_restart_grid(int n_devices, const int *devices, int n_series, int T, int p, int q,
+                         const double *y, const double *u, const double *v, int shared_uv,
+                         const int *cell_offsets, const double *theta0, int niter, double tol,
+                         int algo, double *theta_all, double *lik_all, int *n_iter_all,
+                         int *status_all, int *winner, double *theta_w, double *lik_w,
+                         int *n_iter_w, double *liks_w, double *X, double *Y, double *V,
+                         double *J);
+
+/* Heterogeneous ensembles (R/LDS_reconstruction.R:242-246: list members differ in p and q):
+ * one ldsr_em_restart_grid per group, groups run concurrently (one host thread and one stream
+ * each; group g starts on devices[g % n_devices]).  Fields are the arguments of
+ * ldsr_em_restart_grid; rc receives each group's return code. */
+typedef struct ldsr_group {
+    int n_series, T, p, q, shared_uv;
+    const double *y, *u, *v;
+    const int *cell_offsets;
+    const double *theta0;
+    double *theta_all, *lik_all;
+    int *n_iter_all, *status_all;
+    int *winner;
+    double *theta_w, *lik_w;
+    int *n_iter_w;
+    double *liks_w, *X, *Y, *V, *J;
+    int rc;
+} ldsr_group;
+int ldsr_em_restart_groups(int n_devices, const int *devices, int n_groups, ldsr_group *groups,
+                           int niter, double tol, int algo);
 
 /* Batched LDS_EM.  Host pointers; copies in, runs on `device`, copies out.
  * liks may be NULL; otherwise [n_cells][niter], entries beyond n_iter[c] are NaN. */
@@ -82,19 +135,20 @@ int ldsr_em_batch(int device, int n_series, int T, int p, int q, const double *y
 
 /* Same over several GPUs of one node: the cell grid is cut into n_devices contiguous slices,
  * one host thread per listed device, no collective (restarts never communicate,
- * R/LDS_reconstruction.R:46).  devices[] may repeat an id.  This is what the R shim calls with
- * devices = 0 .. ldsr_device_count()-1. */
+ * R/LDS_reconstruction.R:46).  devices[] may repeat an id. */
 int ldsr_em_batch_multi(int n_devices, const int *devices, int n_series, int T, int p, int q,
                         const double *y, const double *u, const double *v, int shared_uv,
                         const int *cell_offsets, const double *theta0, int niter, double tol,
                         int algo, double *theta, double *lik, int *n_iter, int *status,
                         double *liks);
 
-/* Same with DEVICE pointers (cell_offsets stays a host array).  Asynchronous on `stream`
- * (a hipStream_t passed as void*; NULL = default stream).  workspace: device buffer of at
- * least ldsr_em_workspace_bytes(...) bytes, 256-byte aligned; it holds the prepared series,
- * the block table and the work-queue heads of THIS call, so calls that may overlap in time
- * (different streams) need separate workspaces. */
+/* Same with DEVICE pointers (cell_offsets stays a host array and may be reused or freed as
+ * soon as the call returns).  Asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ * default stream): the call only enqueues work -- the block table travels through a pinned
+ * staging ring owned by the library -- and never waits for the device.  workspace: device
+ * buffer of at least ldsr_em_workspace_bytes(...) bytes, 256-byte aligned; it holds the
+ * prepared series, the block table and the work-queue heads of THIS call, so calls that may
+ * overlap in time (different streams) need separate workspaces. */
 size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int n_cells, int algo);
 int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, int q,
                          const double *d_y, const double *d_u, const double *d_v,
@@ -102,6 +156,11 @@ int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, i
                          int niter, double tol, int algo, double *d_theta, double *d_lik,
                          int *d_n_iter, int *d_status, double *d_liks, void *d_workspace,
                          size_t workspace_bytes);
+
+/* Which kernel a call with these arguments launches: writes its name as rocprofv3 prints it
+ * (e.g. "em_scan_kernel<1, 2, 16, 1, false, false>") into buf and returns the resolved algorithm
+ * (LDSR_ALGO_SERIAL / LDSR_ALGO_SCAN), or a negative value for unsupported arguments. */
+int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len);
 
 /* Batched Kalman_smoother: one E-step for each cell's theta.  Host pointers.
  * X, Y, V, J: [n_cells][T] (any may be NULL); lik: [n_cells].  stdlik as src/EM.cpp:124. */

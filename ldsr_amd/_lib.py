@@ -24,6 +24,12 @@ SIGNATURES = {
     "ldsr_em_batch_multi": (C.c_int, [C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                       _ip, _ip, _dp]),
+    "ldsr_em_restart_grid": (C.c_int, [C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                       C.c_int, _ip, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp,
+                                       _ip, _ip, _ip, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp]),
+    "ldsr_em_restart_groups": (C.c_int, [C.c_int, _ip, C.c_int, _vp, C.c_int, C.c_double, C.c_int]),
+    "ldsr_em_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
+                               C.c_size_t]),
     "ldsr_em_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldsr_em_batch_device": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                        _vp, C.c_int, _ip, _vp, C.c_int, C.c_double, C.c_int, _vp,
@@ -40,6 +46,18 @@ SIGNATURES = {
     "ldsr_profile_collect": (C.c_int, [_dp, _ip]),
     "ldsr_select_restart": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int]),
 }
+
+
+
+class Group(C.Structure):
+    """struct ldsr_group of include/ldsr_hip.h (one member of a heterogeneous ensemble)."""
+    _fields_ = [("n_series", C.c_int), ("T", C.c_int), ("p", C.c_int), ("q", C.c_int),
+                ("shared_uv", C.c_int),
+                ("y", _dp), ("u", _dp), ("v", _dp), ("cell_offsets", _ip), ("theta0", _dp),
+                ("theta_all", _dp), ("lik_all", _dp), ("n_iter_all", _ip), ("status_all", _ip),
+                ("winner", _ip), ("theta_w", _dp), ("lik_w", _dp), ("n_iter_w", _ip),
+                ("liks_w", _dp), ("X", _dp), ("Y", _dp), ("V", _dp), ("J", _dp), ("rc", C.c_int)]
+
 
 _LIB = None
 

@@ -221,18 +221,122 @@ def Mstep(y, u, v, fit, device=0):
     return unpack_theta(th[0], p, q)
 
 
+def _grid_outputs(S, T, P, n, niter, want_all):
+    out = {"winner": np.empty(S, dtype=np.int32), "theta": np.empty((S, P)), "lik": np.empty(S),
+           "n_iter": np.empty(S, dtype=np.int32), "liks": np.empty((S, niter)),
+           "X": np.empty((S, T)), "Y": np.empty((S, T)), "V": np.empty((S, T)),
+           "J": np.empty((S, T))}
+    allr = None
+    if want_all:
+        allr = {"theta": np.empty((n, P)), "lik": np.empty(n), "n_iter": np.empty(n, dtype=np.int32),
+                "status": np.empty(n, dtype=np.int32)}
+    return out, allr
+
+
+def em_restart_grid(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, devices=(0,),
+                    algo=ALGO_AUTO, return_all=True):
+    """LDS_EM_restart for a whole grid of series / CV folds in ONE library call
+    (ldsr_em_restart_grid): every (series, restart) cell runs on the GPU(s), each series'
+    winner is picked by the reference's rule and only the winners' models cross PCIe.
+
+    Returns dict: winner [S] (global cell index, -1 = none), theta [S, P], lik [S], n_iter [S],
+    liks [S, niter] (NaN padded), X / Y / V / J [S, T]; plus "all" (per-cell theta, lik,
+    n_iter, status) when return_all."""
+    Y, U, V, S, T, p, q, shared = _series(y, u, v)
+    theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+    P = 6 + p + q
+    if theta0.ndim != 2 or theta0.shape[1] != P:
+        raise ValueError("theta0 must be [n_cells, %d]" % P)
+    n = theta0.shape[0]
+    if cell_offsets is None:
+        if S != 1:
+            raise ValueError("cell_offsets is required with several series")
+        cell_offsets = [0, n]
+    off = np.ascontiguousarray(cell_offsets, dtype=np.int32)
+    if off.size != S + 1 or off[-1] != n:
+        raise ValueError("cell_offsets must have S+1 entries ending at n_cells")
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    out, allr = _grid_outputs(S, T, P, n, int(niter), return_all)
+    a = allr or {}
+    _lib.check(_lib.lib().ldsr_em_restart_grid(
+        devs.size, _i(devs), S, T, p, q, _d(Y), _d(U), _d(V), shared, _i(off), _d(theta0),
+        int(niter), float(tol), int(algo), _d(a.get("theta")), _d(a.get("lik")),
+        _i(a.get("n_iter")), _i(a.get("status")), _i(out["winner"]), _d(out["theta"]),
+        _d(out["lik"]), _i(out["n_iter"]), _d(out["liks"]), _d(out["X"]), _d(out["Y"]),
+        _d(out["V"]), _d(out["J"])))
+    if allr is not None:
+        out["all"] = allr
+    return out
+
+
+def ensemble_restart(y, members, inits, niter=1000, tol=1e-5, devices=(0,), algo=ALGO_AUTO):
+    """The ensemble loop of LDS_reconstruction (R/LDS_reconstruction.R:242-246): `members` is a
+    list of (u, v) pairs that may differ in p and q (tests/testthat/test-ensemble.R:4-5),
+    `inits` the matching list of packed theta0 arrays [n_restarts, 6+p+q].  All members run
+    concurrently inside ONE library call (ldsr_em_restart_groups); returns one
+    em_restart_grid-style dict per member."""
+    import ctypes as C
+    if len(members) != len(inits):
+        raise ValueError("members and inits must have the same length")
+    G = len(members)
+    groups = (_lib.Group * max(G, 1))()
+    keep, outs = [], []
+    for g, ((u, v), th0) in enumerate(zip(members, inits)):
+        Y, U, V, S, T, p, q, shared = _series(y, u, v)
+        th0 = np.ascontiguousarray(th0, dtype=np.float64)
+        P = 6 + p + q
+        if th0.ndim != 2 or th0.shape[1] != P:
+            raise ValueError("inits[%d] must be [n, %d]" % (g, P))
+        n = th0.shape[0]
+        off = np.array([0, n], dtype=np.int32) if S == 1 else None
+        if off is None:
+            raise ValueError("ensemble members share one y series")
+        out, allr = _grid_outputs(S, T, P, n, int(niter), True)
+        keep.append((Y, U, V, th0, off))
+        outs.append((out, allr))
+        gr = groups[g]
+        gr.n_series, gr.T, gr.p, gr.q, gr.shared_uv = S, T, p, q, shared
+        gr.y, gr.u, gr.v, gr.cell_offsets, gr.theta0 = _d(Y), _d(U), _d(V), _i(off), _d(th0)
+        gr.theta_all, gr.lik_all = _d(allr["theta"]), _d(allr["lik"])
+        gr.n_iter_all, gr.status_all = _i(allr["n_iter"]), _i(allr["status"])
+        gr.winner, gr.theta_w, gr.lik_w, gr.n_iter_w = (_i(out["winner"]), _d(out["theta"]),
+                                                        _d(out["lik"]), _i(out["n_iter"]))
+        gr.liks_w, gr.X, gr.Y, gr.V, gr.J = (_d(out["liks"]), _d(out["X"]), _d(out["Y"]),
+                                             _d(out["V"]), _d(out["J"]))
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    _lib.check(_lib.lib().ldsr_em_restart_groups(devs.size, _i(devs), G, C.byref(groups), int(niter),
+                                                 float(tol), int(algo)))
+    res = []
+    for out, allr in outs:
+        out["all"] = allr
+        res.append(out)
+    return res
+
+
+def _model_from_grid(r, s, p, q):
+    """Row s of an em_restart_grid result in LDS_EM's return shape (src/EM.cpp:276-279)."""
+    n_it = int(r["n_iter"][s])
+    return {"theta": unpack_theta(r["theta"][s], p, q),
+            "fit": {"X": r["X"][s:s + 1].copy(), "Y": r["Y"][s:s + 1].copy(),
+                    "V": r["V"][s:s + 1].copy(), "J": r["J"][s:s + 1].copy(),
+                    "lik": float(r["lik"][s])},
+            "liks": r["liks"][s, :n_it].copy(), "lik": float(r["lik"][s])}
+
+
 def LDS_EM(y, u, v, theta0, niter=1000, tol=1e-5, device=0, algo=ALGO_AUTO):
     """-> {"theta", "fit", "liks", "lik"}   (src/EM.cpp:276-279)"""
     p, q = _dims(u, v)
-    r = em_batch(y, u, v, pack_theta(theta0, p, q)[None, :], niter=niter, tol=tol, device=device,
-                 algo=algo, return_liks=True)
-    if r["status"][0] == 2:
+    r = em_restart_grid(y, u, v, pack_theta(theta0, p, q)[None, :], niter=niter, tol=tol,
+                        devices=(device,), algo=algo)
+    if r["all"]["status"][0] == 2:
         raise _lib.LdsrError("LDS_EM: matrix is singular")
-    th = r["theta"][0]
-    fit = Kalman_smoother(y, u, v, th, device=device)
-    n_it = int(r["n_iter"][0])
-    return {"theta": unpack_theta(th, p, q), "fit": fit, "liks": r["liks"][0, :n_it].copy(),
-            "lik": float(r["lik"][0])}
+    if r["winner"][0] < 0:      # a lone restart with a NaN likelihood: the reference returns it as is
+        b = em_batch(y, u, v, pack_theta(theta0, p, q)[None, :], niter=niter, tol=tol, device=device,
+                     algo=algo, return_liks=True)
+        th = b["theta"][0]
+        return {"theta": unpack_theta(th, p, q), "fit": Kalman_smoother(y, u, v, th, device=device),
+                "liks": b["liks"][0, :int(b["n_iter"][0])].copy(), "lik": float(b["lik"][0])}
+    return _model_from_grid(r, 0, p, q)
 
 
 def select_restart(lik, theta_packed, p, q):
@@ -242,23 +346,22 @@ def select_restart(lik, theta_packed, p, q):
 
 
 def LDS_EM_restart(y, u, v, init, niter=1000, tol=1e-5, return_init=True, device=0,
-                   algo=ALGO_AUTO):
+                   algo=ALGO_AUTO, devices=None):
     """One LDS_EM per element of `init`, all in one GPU launch, then the reference's selection
     (highest likelihood among models with C > 0 if any).  Returns the winning model in LDS_EM's
-    shape (+ "init"), plus "all" = per-restart lik / theta / n_iter / status arrays."""
+    shape (+ "init"), plus "all" = per-restart lik / theta / n_iter / status arrays.  Only the
+    winner's fit and likelihood trace cross PCIe (one ldsr_em_restart_grid call)."""
     p, q = _dims(u, v)
     theta0 = np.stack([pack_theta(t, p, q) for t in init])
-    r = em_batch(y, u, v, theta0, niter=niter, tol=tol, device=device, algo=algo, return_liks=True)
-    if np.any(r["status"] == 2):
+    r = em_restart_grid(y, u, v, theta0, niter=niter, tol=tol,
+                        devices=(device,) if devices is None else devices, algo=algo)
+    if np.any(r["all"]["status"] == 2):
         raise _lib.LdsrError("LDS_EM_restart: matrix is singular")
-    k = select_restart(r["lik"], r["theta"], p, q)
+    k = int(r["winner"][0])
     if k < 0:
         raise _lib.LdsrError("LDS_EM_restart: no restart produced a finite likelihood")
-    th = r["theta"][k]
-    ans = {"theta": unpack_theta(th, p, q), "fit": Kalman_smoother(y, u, v, th, device=device),
-           "liks": r["liks"][k, :int(r["n_iter"][k])].copy(), "lik": float(r["lik"][k])}
+    ans = _model_from_grid(r, 0, p, q)
     if return_init:
         ans["init"] = init[k]
-    ans["all"] = {"lik": r["lik"], "theta": r["theta"], "n_iter": r["n_iter"],
-                  "status": r["status"], "selected": k}
+    ans["all"] = dict(r["all"], selected=k)
     return ans

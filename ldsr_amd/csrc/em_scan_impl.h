@@ -271,7 +271,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             prm.lik[cell] = NAN;
             prm.n_iter[cell] = 0;
             prm.status[cell] = 2;
-            if (prm.liks)
+            if (prm.liks && prm.liks_nanfill)
                 for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
         }
         return;
@@ -618,7 +618,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     if (lane == 0) {
         store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
-        if (prm.liks)
+        if (prm.liks && prm.liks_nanfill)
             for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
         prm.lik[cell] = lik;
         prm.n_iter[cell] = it;

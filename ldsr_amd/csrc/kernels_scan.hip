@@ -1,6 +1,8 @@
 // kernels_scan.hip -- chooses the chunk length L (time steps per lane) of the wave-per-cell
 // scan kernel and dispatches to the per-L translation units (em_scan_L*.hip).
 #include "em_scan_impl.h"
+#include <cstdio>
+
 #include "ldsr_kernels.h"
 
 // smallest compiled chunk length with T <= 64*L; every choice also satisfies L*(L-1) <= T
@@ -28,13 +30,22 @@ bool em_scan_global_image(int T, int PP, int QQ) {
     return L >= 20 && PP <= 8 && QQ <= 8 && !lds_image_fits(L, PP, QQ);
 }
 
-int em_scan_waves_per_block(int T, int PP, int QQ) {
+int em_scan_cells_per_block(int T, int PP, int QQ) {
     if (em_scan_global_image(T, PP, QQ)) return 4;     // no LDS image: two workgroups per CU by VGPRs
     return scan_wpb(scan_L_for(T), PP, QQ);
 }
 
-hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int wpb, bool queue,
+bool em_scan_queue_only(int T, int PP, int QQ) { return em_scan_global_image(T, PP, QQ); }
+
+void em_scan_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len) {
+    const bool gimg = em_scan_global_image(T, PP, QQ);
+    snprintf(buf, len, "em_scan_kernel<%d, %d, %d, %s, %s>", PP, QQ, scan_L_for(T),
+             (queue || gimg) ? "true" : "false", gimg ? "true" : "false");
+}
+
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
                           hipStream_t stream) {
+    const int wpb = em_scan_cells_per_block(prm.T, PP, QQ);
     if (em_scan_global_image(prm.T, PP, QQ)) queue = true;   // GIMG exists with the queue schedule only
     switch (scan_L_for(prm.T)) {
         case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, queue, stream);

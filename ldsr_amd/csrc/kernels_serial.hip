@@ -8,6 +8,8 @@
 // of a wavefront store and load it coalesced.  The fast path for T <= 2048 is the
 // wave-per-cell scan kernel in kernels_scan.hip.
 #include "ldsr_device.h"
+#include <cstdio>
+
 #include "ldsr_kernels.h"
 
 // ---------------------------------------------------------------------------------------
@@ -219,6 +221,8 @@ __global__ __launch_bounds__(64) void em_serial_kernel(EmParams prm) {
         prm.lik[cell] = NAN;
         prm.n_iter[cell] = 0;
         prm.status[cell] = 2;
+        if (prm.liks && prm.liks_nanfill)
+            for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
         return;
     }
 
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64) void em_serial_kernel(EmParams prm) {
         mstep_update(th, S, sc, T);
     }
     store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
-    if (prm.liks)
+    if (prm.liks && prm.liks_nanfill)
         for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
     prm.lik[cell] = lik;
     prm.n_iter[cell] = it;
@@ -383,8 +387,9 @@ __global__ __launch_bounds__(64) void smooth_kernel(SmoothParams prm) {
 
     double Xs = Xu, Vs = Vu;
     double ssq = 0.0;   // sum_t (Xs_{t+1} - A Xs_t - B u_t)^2, the penalty of R/LDS_GA.R:34-40
-    J[T - 1] = Vu * th.A / (th.A * Vu * th.A + th.Q);  // src/EM.cpp:98
-    {
+    const bool full = !prm.scalar_only;
+    if (full) {
+        J[T - 1] = Vu * th.A / (th.A * Vu * th.A + th.Q);  // src/EM.cpp:98
         double dv = 0.0;
 #pragma unroll
         for (int k = 0; k < QQ; k++) dv = fma(th.D[k], v[(T - 1) * QQ + k], dv);
@@ -405,13 +410,15 @@ __global__ __launch_bounds__(64) void smooth_kernel(SmoothParams prm) {
             const double d = Xs1 - th.A * Xs - bu;
             ssq += d * d;
         }
-        double dv = 0.0;
+        if (full) {
+            double dv = 0.0;
 #pragma unroll
-        for (int k = 0; k < QQ; k++) dv = fma(th.D[k], v[t * QQ + k], dv);
-        X[t] = Xs;
-        V[t] = Vs;
-        J[t] = Jt;
-        Y[t] = th.C * Xs + dv;
+            for (int k = 0; k < QQ; k++) dv = fma(th.D[k], v[t * QQ + k], dv);
+            X[t] = Xs;
+            V[t] = Vs;
+            J[t] = Jt;
+            Y[t] = th.C * Xs + dv;
+        }
     }
     if (prm.pen) prm.pen[cell] = lik - prm.lambda * ssq;
 }
@@ -510,6 +517,34 @@ __global__ __launch_bounds__(64) void mstep_kernel(SmoothParams prm) {
         case 16 * 32 + 16: { constexpr int PP = 16, QQ = 16; CALL; } break;               \
         default: return hipErrorInvalidValue;                                           \
     }
+
+// ---------------------------------------------------------------------------------------
+// gather_winners_kernel: one block per winner; copies its theta / theta0 rows and its
+// likelihood trace (NaN padded beyond n_iter) into the compact winner arrays.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void gather_winners_kernel(GatherParams prm) {
+    const int i = blockIdx.x;
+    const long c = prm.cell[i];
+    for (int k = threadIdx.x; k < prm.P; k += 128) {
+        prm.theta_w[(long)i * prm.P + k] = prm.theta[c * prm.P + k];
+        prm.theta0_w[(long)i * prm.P + k] = prm.theta0[c * prm.P + k];
+    }
+    if (prm.liks) {
+        const int n = prm.n_iter[c];
+        for (int k = threadIdx.x; k < prm.niter; k += 128)
+            prm.liks_w[(long)i * prm.niter + k] = k < n ? prm.liks[c * prm.niter + k] : NAN;
+    }
+}
+
+hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream) {
+    hipLaunchKernelGGL(gather_winners_kernel, dim3(prm.n_w), dim3(128), 0, stream, prm);
+    return hipGetLastError();
+}
+
+void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len) {
+    const bool stage = (size_t)T * (1 + PP + QQ) * sizeof(double) <= 64 * 1024;
+    snprintf(buf, len, "em_serial_kernel<%d, %d, %s>", PP, QQ, stage ? "true" : "false");
+}
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream) {
     hipLaunchKernelGGL(series_prep_kernel, dim3(n_series), dim3(256), 0, stream, prm);

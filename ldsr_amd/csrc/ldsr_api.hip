@@ -1,10 +1,14 @@
-// ldsr_api.hip -- the C ABI of include/ldsr_hip.h: argument checks, workspace carving,
-// block tables, launches.  No numerics live here.
+// ldsr_api.hip -- the C ABI of include/ldsr_hip.h: argument checks, device arenas, workspace
+// carving, block tables, launches, restart selection.  No numerics live here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,7 +31,7 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *ldsr_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ldsr_version(void) { return "ldsr_hip 0.1.0 (gfx950)"; }
+extern "C" const char *ldsr_version(void) { return "ldsr_hip 0.2.0 (gfx950)"; }
 
 extern "C" int ldsr_device_count(void) {
     int n = 0;
@@ -35,24 +39,35 @@ extern "C" int ldsr_device_count(void) {
     return n;
 }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 // ---- optional kernel timer: HIP events around the EM kernel, on its launch stream ------------
+// Slots are handed out under a mutex (ldsr_em_batch_multi / _groups call in from worker
+// threads); an event pair belongs to the device it was created on.
+struct ProfSlot {
+    int device;
+    hipEvent_t a, b;
+};
 static struct {
+    std::mutex mu;
     bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<ProfSlot> ev;
     size_t used = 0;
 } g_prof;
 
 extern "C" void ldsr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;
     g_prof.used = 0;
 }
 
 extern "C" int ldsr_profile_collect(double *total_ms, int *n_launches) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     double tot = 0.0;
     for (size_t i = 0; i < g_prof.used; i++) {
-        HIPCHK(hipEventSynchronize(g_prof.ev[i].second));
+        HIPCHK(hipEventSynchronize(g_prof.ev[i].b));
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second));
+        HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[i].a, g_prof.ev[i].b));
         tot += ms;
     }
     if (total_ms) *total_ms = tot;
@@ -61,40 +76,209 @@ extern "C" int ldsr_profile_collect(double *total_ms, int *n_launches) {
     return LDSR_OK;
 }
 
-static hipError_t prof_mark(hipStream_t stream, bool end) {
+// Records the start event and returns the slot (-1 when the timer is off).
+static hipError_t prof_begin(int device, hipStream_t stream, int *slot) {
+    *slot = -1;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     if (!g_prof.on) return hipSuccess;
-    if (!end) {
-        if (g_prof.used == g_prof.ev.size()) {
-            hipEvent_t a, b;
-            hipError_t e = hipEventCreate(&a);
-            if (e != hipSuccess) return e;
-            e = hipEventCreate(&b);
-            if (e != hipSuccess) return e;
-            g_prof.ev.emplace_back(a, b);
-        }
-        return hipEventRecord(g_prof.ev[g_prof.used].first, stream);
+    if (g_prof.used == g_prof.ev.size()) {
+        ProfSlot s;
+        s.device = device;
+        hipError_t e = hipEventCreate(&s.a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&s.b);
+        if (e != hipSuccess) return e;
+        g_prof.ev.push_back(s);
+    } else if (g_prof.ev[g_prof.used].device != device) {
+        ProfSlot &s = g_prof.ev[g_prof.used];
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+        s.device = device;
+        hipError_t e = hipEventCreate(&s.a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&s.b);
+        if (e != hipSuccess) return e;
     }
-    return hipEventRecord(g_prof.ev[g_prof.used++].second, stream);
+    *slot = (int)g_prof.used++;
+    return hipEventRecord(g_prof.ev[*slot].a, stream);
+}
+
+static hipError_t prof_end(hipStream_t stream, int slot) {
+    if (slot < 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    return hipEventRecord(g_prof.ev[slot].b, stream);
+}
+
+// ---- pinned staging ring: small host tables that must reach the device asynchronously --------
+// ldsr_em_batch_device promises to only enqueue work, so its block table cannot be copied from
+// the caller's (or a function-local) pageable memory: it is written into a library-owned pinned
+// slot, copied from there on the caller's stream, and the slot is recycled once its event has
+// completed (normally long before the ring wraps around).
+struct StageSlot {
+    int device = -1;
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+static struct {
+    std::mutex mu;
+    StageSlot slot[16];
+    unsigned next = 0;
+} g_stage;
+
+static int stage_h2d_async(int device, hipStream_t stream, void *dst, const void *src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    StageSlot &s = g_stage.slot[g_stage.next++ % 16];
+    if (s.pending) {
+        HIPCHK(hipEventSynchronize(s.ev));
+        s.pending = false;
+    }
+    if (s.device != device && s.ev) {       // events belong to a device
+        (void)hipEventDestroy(s.ev);
+        s.ev = nullptr;
+    }
+    if (!s.ev) HIPCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    s.device = device;
+    if (s.cap < bytes) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr;
+        s.cap = 0;
+        const size_t cap = std::max(align256(bytes) * 2, (size_t)16384);
+        HIPCHK(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+        s.cap = cap;
+    }
+    memcpy(s.host, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, s.host, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(s.ev, stream));
+    s.pending = true;
+    return LDSR_OK;
+}
+
+// ---- device arenas of the host-pointer entry points -------------------------------------------
+// One arena = one device block + one pinned host block (both grow-only) + one non-blocking
+// stream.  A call leases a free arena of its device (or creates one), so concurrent callers never
+// share buffers, and repeated calls of the same shape do no hipMalloc / hipFree at all.
+struct Arena {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *dev = nullptr, *pin = nullptr;
+    size_t dev_cap = 0, pin_cap = 0;
+    bool busy = false;
+};
+static std::mutex g_arena_mu;
+static std::vector<Arena *> g_arenas;
+
+static int arena_acquire(int device, Arena **out) {
+    HIPCHK(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (Arena *a : g_arenas)
+        if (a->device == device && !a->busy) {
+            a->busy = true;
+            *out = a;
+            return LDSR_OK;
+        }
+    Arena *a = new Arena;
+    a->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete a;
+        return fail(LDSR_EHIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+    }
+    a->busy = true;
+    g_arenas.push_back(a);
+    *out = a;
+    return LDSR_OK;
+}
+
+static void arena_release(Arena *a) {
+    if (!a) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    a->busy = false;
+}
+
+struct ArenaLease {     // releases on scope exit
+    Arena *a = nullptr;
+    ~ArenaLease() { arena_release(a); }
+};
+
+static int arena_reserve(Arena *a, size_t dev_bytes, size_t pin_bytes) {
+    if (dev_bytes > a->dev_cap) {
+        HIPCHK(hipStreamSynchronize(a->stream));
+        if (a->dev) (void)hipFree(a->dev);
+        a->dev = nullptr;
+        a->dev_cap = 0;
+        const size_t cap = align256(dev_bytes + dev_bytes / 8);
+        HIPCHK(hipMalloc((void **)&a->dev, cap));
+        a->dev_cap = cap;
+    }
+    if (pin_bytes > a->pin_cap) {
+        HIPCHK(hipStreamSynchronize(a->stream));
+        if (a->pin) (void)hipHostFree(a->pin);
+        a->pin = nullptr;
+        a->pin_cap = 0;
+        const size_t cap = align256(pin_bytes + pin_bytes / 8);
+        HIPCHK(hipHostMalloc((void **)&a->pin, cap, hipHostMallocDefault));
+        a->pin_cap = cap;
+    }
+    return LDSR_OK;
 }
 
 extern "C" void ldsr_shutdown(void) {
-    for (auto &p : g_prof.ev) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+    {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        for (auto &p : g_prof.ev) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        g_prof.ev.clear();
+        g_prof.used = 0;
     }
-    g_prof.ev.clear();
-    g_prof.used = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_stage.mu);
+        for (StageSlot &s : g_stage.slot) {
+            if (s.pending) (void)hipEventSynchronize(s.ev);
+            if (s.ev) (void)hipEventDestroy(s.ev);
+            if (s.host) (void)hipHostFree(s.host);
+            s = StageSlot();
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    std::vector<Arena *> keep;
+    for (Arena *a : g_arenas) {
+        if (a->busy) {          // a call is still running on another thread: leave it alone
+            keep.push_back(a);
+            continue;
+        }
+        if (hipSetDevice(a->device) == hipSuccess) {
+            (void)hipStreamSynchronize(a->stream);
+            if (a->dev) (void)hipFree(a->dev);
+            if (a->pin) (void)hipHostFree(a->pin);
+            (void)hipStreamDestroy(a->stream);
+        }
+        delete a;
+    }
+    g_arenas.swap(keep);
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// bump allocator over an arena block: first pass sizes, second pass hands out pointers
+struct Carver {
+    size_t o = 0;
+    size_t take(size_t bytes) {
+        const size_t r = o;
+        o = align256(o + (bytes ? bytes : 8));
+        return r;
+    }
+};
 
+// ---- algorithm choice / workspace layout -------------------------------------------------------
 static int resolve_algo(int algo, int T, int PP, int QQ) {
     if (algo == LDSR_ALGO_AUTO) return em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
     return algo;
 }
 
 static int cells_per_block(int algo, int T, int PP, int QQ) {
-    return algo == LDSR_ALGO_SCAN ? em_scan_waves_per_block(T, PP, QQ) : 64;
+    return algo == LDSR_ALGO_SCAN ? em_scan_cells_per_block(T, PP, QQ) : 64;
 }
 
 struct WsLayout {
@@ -139,6 +323,12 @@ static int check_common(int n_series, int T, int p, int q, const double *y,
     return LDSR_OK;
 }
 
+static int check_em(int niter, double tol) {
+    if (niter < 2) return fail(LDSR_EINVAL, "niter must be >= 2 (the reference reads lik[1], src/EM.cpp:256)");
+    if (!(tol >= 0.0)) return fail(LDSR_EINVAL, "tol must be >= 0");
+    return LDSR_OK;
+}
+
 extern "C" size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int n_cells,
                                           int algo) {
     if (n_series < 1 || T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || n_cells < 0)
@@ -148,6 +338,28 @@ extern "C" size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ)) return 0;
     // the layout for shared_uv = 0 is an upper bound for shared_uv = 1
     return ws_layout(n_series, T, PP, QQ, 0, n_cells, algo, cells_per_block(algo, T, PP, QQ)).total;
+}
+
+// scan kernel: cells converge at their own pace (tol > 0) -> per-series work queue
+static bool scan_uses_queue(int T, int PP, int QQ, double tol) {
+    return tol > 0.0 || em_scan_queue_only(T, PP, QQ);
+}
+
+extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf,
+                            size_t len) {
+    if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
+        return -1;
+    const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    algo = resolve_algo(algo, T, PP, QQ);
+    if (algo == LDSR_ALGO_SCAN) {
+        if (!em_scan_supported(T, PP, QQ)) return -1;
+        if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), buf, len);
+    } else if (algo == LDSR_ALGO_SERIAL) {
+        if (buf && len) em_serial_kernel_name(T, PP, QQ, buf, len);
+    } else {
+        return -1;
+    }
+    return algo;
 }
 
 // Runs series_prep on `stream` and fills the workspace pointers.
@@ -167,16 +379,18 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     return LDSR_OK;
 }
 
-extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int T, int p, int q,
-                                    const double *d_y, const double *d_u, const double *d_v,
-                                    int shared_uv, const int *cell_offsets,
-                                    const double *d_theta0, int niter, double tol, int algo,
-                                    double *d_theta, double *d_lik, int *d_n_iter, int *d_status,
-                                    double *d_liks, void *d_workspace, size_t workspace_bytes) {
+// liks_nanfill: entries of d_liks beyond a cell's n_iter are set to NaN (the ABI contract of the
+// batch entry points); the restart-grid path reads only the first n_iter entries and skips it.
+static int em_batch_device_impl(int device, hipStream_t stream, int n_series, int T, int p, int q,
+                                const double *d_y, const double *d_u, const double *d_v,
+                                int shared_uv, const int *cell_offsets, const double *d_theta0,
+                                int niter, double tol, int algo, double *d_theta, double *d_lik,
+                                int *d_n_iter, int *d_status, double *d_liks, int liks_nanfill,
+                                void *d_workspace, size_t workspace_bytes) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
-    if (niter < 2) return fail(LDSR_EINVAL, "niter must be >= 2 (the reference reads lik[1], src/EM.cpp:256)");
-    if (!(tol >= 0.0)) return fail(LDSR_EINVAL, "tol must be >= 0");
+    rc = check_em(niter, tol);
+    if (rc) return rc;
     if (!d_theta0 || !d_theta || !d_lik || !d_n_iter || !d_status || !d_workspace)
         return fail(LDSR_EINVAL, "NULL output / workspace pointer");
     const int n_cells = cell_offsets[n_series];
@@ -185,14 +399,13 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN) return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
-        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 2048 and p, q <= 8");
+        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8");
     const int cpb = cells_per_block(algo, T, PP, QQ);
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo, cpb);
     if (workspace_bytes < L.total)
         return fail(LDSR_EINVAL, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (((size_t)d_workspace & 255) != 0) return fail(LDSR_EINVAL, "workspace must be 256-byte aligned");
     HIPCHK(hipSetDevice(device));
-    hipStream_t stream = (hipStream_t)stream_;
     char *ws = (char *)d_workspace;
 
     rc = prepare_series(stream, n_series, T, p, q, PP, QQ, d_y, d_u, d_v, shared_uv, ws, L);
@@ -203,9 +416,7 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     // of the block).  Work queue (scan kernel, tol > 0): (series, first cell of the SERIES, n
     // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
     // converges early takes the next one instead of idling.
-    const bool use_queue = algo == LDSR_ALGO_SCAN && (tol > 0.0 || em_scan_global_image(T, PP, QQ));
-    std::vector<int> tab;
-    tab.reserve(3 * (size_t)L.max_blocks);
+    const bool use_queue = algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol);
     std::vector<int> bs, bc, bn;
     for (int s = 0; s < n_series; s++)
         for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
@@ -220,15 +431,19 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
         }
     const int n_blocks = (int)bs.size();
     if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow");
+    std::vector<int> tab;
+    tab.reserve(3 * (size_t)n_blocks);
     tab.insert(tab.end(), bs.begin(), bs.end());
     tab.insert(tab.end(), bc.begin(), bc.end());
     tab.insert(tab.end(), bn.begin(), bn.end());
     int *d_tab = (int *)(ws + L.blk);
-    HIPCHK(hipMemcpyAsync(d_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream));
+    rc = stage_h2d_async(device, stream, d_tab, tab.data(), sizeof(int) * tab.size());
+    if (rc) return rc;
 
     EmParams prm;
     prm.T = T; prm.p = p; prm.q = q; prm.has_u = d_u != nullptr; prm.has_v = d_v != nullptr;
     prm.niter = niter; prm.n_cells = n_cells; prm.tol = tol;
+    prm.liks_nanfill = liks_nanfill;
     prm.yp = (const double *)(ws + L.yp);
     prm.yz = (const double *)(ws + L.yz);
     prm.up = (const double *)(ws + L.up);
@@ -245,98 +460,305 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     prm.queue = (int *)(ws + L.queue);
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
-    HIPCHK(prof_mark(stream, false));
+    int slot;
+    HIPCHK(prof_begin(device, stream, &slot));
     if (algo == LDSR_ALGO_SCAN)
-        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, cpb, use_queue, stream));
+        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, stream));
     else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
-    HIPCHK(prof_mark(stream, true));
+    HIPCHK(prof_end(stream, slot));
     return LDSR_OK;
 }
 
-// RAII holder for temporary device buffers of the host-pointer entry points.
-struct DevBufs {
-    std::vector<void *> ptrs;
-    ~DevBufs() {
-        for (void *p : ptrs) (void)hipFree(p);
-    }
-    template <typename Tp>
-    hipError_t alloc(Tp **out, size_t n) {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, n ? n * sizeof(Tp) : sizeof(Tp));
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = (Tp *)p;
-        return e;
-    }
-};
-
-struct HostInputs {
-    double *d_y = nullptr, *d_u = nullptr, *d_v = nullptr;
-};
-
-static int upload_inputs(DevBufs &B, HostInputs &H, int n_series, int T, int p, int q,
-                         const double *y, const double *u, const double *v, int shared_uv) {
-    const size_t nuv = shared_uv ? 1 : (size_t)n_series;
-    HIPCHK(B.alloc(&H.d_y, (size_t)n_series * T));
-    HIPCHK(hipMemcpy(H.d_y, y, sizeof(double) * (size_t)n_series * T, hipMemcpyHostToDevice));
-    if (u) {
-        HIPCHK(B.alloc(&H.d_u, nuv * T * p));
-        HIPCHK(hipMemcpy(H.d_u, u, sizeof(double) * nuv * T * p, hipMemcpyHostToDevice));
-    }
-    if (v) {
-        HIPCHK(B.alloc(&H.d_v, nuv * T * q));
-        HIPCHK(hipMemcpy(H.d_v, v, sizeof(double) * nuv * T * q, hipMemcpyHostToDevice));
-    }
-    return LDSR_OK;
+extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int T, int p, int q,
+                                    const double *d_y, const double *d_u, const double *d_v,
+                                    int shared_uv, const int *cell_offsets,
+                                    const double *d_theta0, int niter, double tol, int algo,
+                                    double *d_theta, double *d_lik, int *d_n_iter, int *d_status,
+                                    double *d_liks, void *d_workspace, size_t workspace_bytes) {
+    return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
+                                shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
+                                d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes);
 }
 
-extern "C" int ldsr_em_batch(int device, int n_series, int T, int p, int q, const double *y,
-                             const double *u, const double *v, int shared_uv,
-                             const int *cell_offsets, const double *theta0, int niter, double tol,
-                             int algo, double *theta, double *lik, int *n_iter, int *status,
-                             double *liks) {
-    int rc = check_common(n_series, T, p, q, y, cell_offsets);
+// ---- one contiguous slice of the cell grid on one device ---------------------------------------
+// Phase 1 (slice_run): ONE pinned->device copy of [y | u | v | theta0], series_prep + EM kernel,
+// ONE device->pinned copy of [theta | lik | n_iter | status].  Phase 2 (slice_fit_winners, the
+// restart-grid entry only): gather the winners' theta and likelihood traces on the device, one
+// smoother pass for them, one copy back.  The arena stays leased between the phases.
+struct Slice {
+    // inputs (host pointers already offset to the slice; `off` are local cell offsets)
+    int device = 0, n_series = 0, T = 0, p = 0, q = 0, shared_uv = 0, niter = 0, algo = 0;
+    double tol = 0.0;
+    const double *y = nullptr, *u = nullptr, *v = nullptr, *theta0 = nullptr;
+    std::vector<int> off;
+    // host outputs of phase 1 (liks optional: the full [n_cells][niter] trace, NaN padded)
+    double *theta = nullptr, *lik = nullptr, *liks = nullptr;
+    int *n_iter = nullptr, *status = nullptr;
+    int max_winners = 0;        // > 0: reserve phase-2 buffers and keep the traces on the device
+    // state
+    ArenaLease lease;
+    int n_cells = 0, PP = 0, QQ = 0, P = 0;
+    bool trace_on_device = false;
+    WsLayout L;
+    size_t wsb = 0;
+    size_t d_in = 0, d_y = 0, d_u = 0, d_v = 0, d_th0 = 0, in_bytes = 0;      // device offsets
+    size_t d_out = 0, d_theta = 0, d_lik = 0, d_nit = 0, d_st = 0, out_bytes = 0;
+    size_t d_liks = 0, d_ws = 0;
+    size_t d_w = 0, w_bytes = 0;          // phase-2 device block
+    size_t p_in = 0, p_out = 0, p_w = 0;  // pinned offsets
+};
+
+static size_t liks_trace_cap_bytes() {
+    const char *e = getenv("LDSR_LIKS_TRACE_MAX_BYTES");
+    if (e && *e) return (size_t)strtoull(e, nullptr, 10);
+    return (size_t)8 << 30;
+}
+
+// phase-2 block layout for n winners (offsets relative to its start)
+struct WinLayout {
+    size_t cell, ser, theta, liks, X, Y, V, J, lik, st, theta0, total;
+    size_t out_begin, out_bytes;    // [theta | liks | X | Y | V | J | lik] is copied back
+};
+static WinLayout win_layout(int n, int P, int T, int niter) {
+    WinLayout W;
+    Carver c;
+    W.cell = c.take(sizeof(int) * n);
+    W.ser = c.take(sizeof(int) * n);
+    W.theta0 = c.take(sizeof(double) * n * P);
+    W.st = c.take(sizeof(int) * n);
+    W.out_begin = c.o;
+    W.theta = c.take(sizeof(double) * n * P);
+    W.liks = c.take(sizeof(double) * (size_t)n * niter);
+    W.X = c.take(sizeof(double) * (size_t)n * T);
+    W.Y = c.take(sizeof(double) * (size_t)n * T);
+    W.V = c.take(sizeof(double) * (size_t)n * T);
+    W.J = c.take(sizeof(double) * (size_t)n * T);
+    W.lik = c.take(sizeof(double) * n);
+    W.out_bytes = c.o - W.out_begin;
+    W.total = c.o;
+    return W;
+}
+
+static int slice_run(Slice &S) {
+    S.n_cells = S.off[S.n_series];
+    S.P = 6 + S.p + S.q;
+    S.PP = ldsr_pad_dim(S.p);
+    S.QQ = ldsr_pad_dim(S.q);
+    if (S.n_cells == 0) return LDSR_OK;
+    const int T = S.T, P = S.P, n = S.n_cells;
+    const size_t nuv = S.shared_uv ? 1 : (size_t)S.n_series;
+    int rc = arena_acquire(S.device, &S.lease.a);
     if (rc) return rc;
-    if (niter < 2) return fail(LDSR_EINVAL, "niter must be >= 2 (the reference reads lik[1], src/EM.cpp:256)");
-    if (!theta0 || !theta || !lik || !n_iter || !status) return fail(LDSR_EINVAL, "NULL pointer");
+    Arena *A = S.lease.a;
+
+    Carver c;
+    S.d_in = c.o;
+    S.d_y = c.take(sizeof(double) * (size_t)S.n_series * T);
+    S.d_u = c.take(S.u ? sizeof(double) * nuv * T * S.p : 0);
+    S.d_v = c.take(S.v ? sizeof(double) * nuv * T * S.q : 0);
+    S.d_th0 = c.take(sizeof(double) * (size_t)n * P);
+    S.in_bytes = c.o - S.d_in;
+    S.d_out = c.o;
+    S.d_theta = c.take(sizeof(double) * (size_t)n * P);
+    S.d_lik = c.take(sizeof(double) * (size_t)n);
+    S.d_nit = c.take(sizeof(int) * (size_t)n);
+    S.d_st = c.take(sizeof(int) * (size_t)n);
+    S.out_bytes = c.o - S.d_out;
+    const size_t trace_bytes = sizeof(double) * (size_t)n * S.niter;
+    S.trace_on_device = S.liks != nullptr || (S.max_winners > 0 && trace_bytes <= liks_trace_cap_bytes());
+    S.d_liks = c.take(S.trace_on_device ? trace_bytes : 0);
+    S.wsb = ldsr_em_workspace_bytes(S.n_series, T, S.p, S.q, n, S.algo);
+    if (!S.wsb) return fail(LDSR_EINVAL, "unsupported (T, p, q, algo) combination");
+    {   // the layout em_batch_device_impl will carve out of the workspace (phase 2 reuses it)
+        const int a = resolve_algo(S.algo, T, S.PP, S.QQ);
+        S.L = ws_layout(S.n_series, T, S.PP, S.QQ, S.shared_uv, n, a, cells_per_block(a, T, S.PP, S.QQ));
+    }
+    S.d_ws = c.take(S.wsb);
+    const WinLayout W = win_layout(std::max(S.max_winners, 1), P, T, S.niter);
+    S.d_w = c.take(S.max_winners > 0 ? W.total : 0);
+    S.w_bytes = S.max_winners > 0 ? W.total : 0;
+    const size_t dev_total = c.o;
+    // pinned: inputs, outputs, phase-2 block (same relative layouts as on the device)
+    S.p_in = 0;
+    S.p_out = align256(S.in_bytes);
+    S.p_w = S.p_out + align256(S.out_bytes);
+    const size_t pin_total = S.p_w + S.w_bytes;
+    rc = arena_reserve(A, dev_total, pin_total);
+    if (rc) return rc;
+
+    // stage inputs
+    char *pin = A->pin + S.p_in;
+    memcpy(pin + (S.d_y - S.d_in), S.y, sizeof(double) * (size_t)S.n_series * T);
+    if (S.u) memcpy(pin + (S.d_u - S.d_in), S.u, sizeof(double) * nuv * T * S.p);
+    if (S.v) memcpy(pin + (S.d_v - S.d_in), S.v, sizeof(double) * nuv * T * S.q);
+    memcpy(pin + (S.d_th0 - S.d_in), S.theta0, sizeof(double) * (size_t)n * P);
+    HIPCHK(hipMemcpyAsync(A->dev + S.d_in, pin, S.in_bytes, hipMemcpyHostToDevice, A->stream));
+
+    rc = em_batch_device_impl(
+        S.device, A->stream, S.n_series, T, S.p, S.q, (const double *)(A->dev + S.d_y),
+        S.u ? (const double *)(A->dev + S.d_u) : nullptr, S.v ? (const double *)(A->dev + S.d_v) : nullptr,
+        S.shared_uv, S.off.data(), (const double *)(A->dev + S.d_th0), S.niter, S.tol, S.algo,
+        (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
+        (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
+        S.liks != nullptr, A->dev + S.d_ws, S.wsb);
+    if (rc) return rc;
+    char *pout = A->pin + S.p_out;
+    HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
+    HIPCHK(hipStreamSynchronize(A->stream));
+    memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
+    memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
+    memcpy(S.n_iter, pout + (S.d_nit - S.d_out), sizeof(int) * (size_t)n);
+    memcpy(S.status, pout + (S.d_st - S.d_out), sizeof(int) * (size_t)n);
+    if (S.liks)     // the full trace goes straight to the caller's (pageable) array
+        HIPCHK(hipMemcpy(S.liks, A->dev + S.d_liks, trace_bytes, hipMemcpyDeviceToHost));
+    return LDSR_OK;
+}
+
+// Phase 2.  w_series / w_cell: local series index and local cell index of each winner of this
+// slice; outputs are rows [i] of the given host arrays (any of liks_w .. J may be NULL).
+static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *w_cell,
+                             double *liks_w, double *X, double *Y, double *V, double *J) {
+    if (n_w == 0) return LDSR_OK;
+    Arena *A = S.lease.a;
+    const int T = S.T, P = S.P, niter = S.niter;
+    HIPCHK(hipSetDevice(S.device));
+    const WinLayout W = win_layout(std::max(S.max_winners, 1), P, T, niter);
+    char *dw = A->dev + S.d_w, *pw = A->pin + S.p_w;
+    memcpy(pw + W.cell, w_cell, sizeof(int) * n_w);
+    memcpy(pw + W.ser, w_series, sizeof(int) * n_w);
+    HIPCHK(hipMemcpyAsync(dw + W.cell, pw + W.cell, W.ser + sizeof(int) * n_w - W.cell,
+                          hipMemcpyHostToDevice, A->stream));
+    GatherParams gp;
+    gp.n_w = n_w; gp.P = P; gp.niter = niter;
+    gp.cell = (const int *)(dw + W.cell);
+    gp.theta = (const double *)(A->dev + S.d_theta);
+    gp.theta0 = (const double *)(A->dev + S.d_th0);
+    gp.n_iter = (const int *)(A->dev + S.d_nit);
+    gp.liks = S.trace_on_device ? (const double *)(A->dev + S.d_liks) : nullptr;
+    gp.theta_w = (double *)(dw + W.theta);
+    gp.theta0_w = (double *)(dw + W.theta0);
+    gp.liks_w = (double *)(dw + W.liks);
+    HIPCHK(launch_gather_winners(gp, A->stream));
+    char *ws = A->dev + S.d_ws;
+    if (!S.trace_on_device && liks_w) {
+        // the per-cell traces were too large to keep: re-run the winners alone (one cell per
+        // series; a cell's result does not depend on its position in the grid) with a trace
+        std::vector<int> sel_off((size_t)S.n_series + 1, 0), order((size_t)n_w);
+        for (int i = 0; i < n_w; i++) sel_off[(size_t)w_series[i] + 1] = 1;
+        for (int s = 0; s < S.n_series; s++) sel_off[(size_t)s + 1] += sel_off[(size_t)s];
+        for (int i = 1; i < n_w; i++)
+            if (w_series[i] <= w_series[i - 1]) return fail(LDSR_EINVAL, "internal: winners must be sorted by series");
+        const size_t nuv = S.shared_uv ? 1 : (size_t)S.n_series;
+        (void)nuv;
+        int rc = em_batch_device_impl(
+            S.device, A->stream, S.n_series, T, S.p, S.q, (const double *)(A->dev + S.d_y),
+            S.u ? (const double *)(A->dev + S.d_u) : nullptr, S.v ? (const double *)(A->dev + S.d_v) : nullptr,
+            S.shared_uv, sel_off.data(), (const double *)(dw + W.theta0), niter, S.tol, S.algo,
+            (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
+            (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb);
+        if (rc) return rc;
+    }
+    // the winners' fit: one smoother pass at theta_w on the prepared series
+    SmoothParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.T = T; sp.p = S.p; sp.q = S.q; sp.has_u = S.u != nullptr; sp.has_v = S.v != nullptr;
+    sp.n_cells = n_w; sp.stdlik = 1; sp.mode = 0;
+    sp.yp = (const double *)(ws + S.L.yp);
+    sp.up = (const double *)(ws + S.L.up);
+    sp.vp = (const double *)(ws + S.L.vp);
+    sp.u_stride = S.shared_uv ? 0 : (long)T * S.PP;
+    sp.v_stride = S.shared_uv ? 0 : (long)T * S.QQ;
+    sp.sc = (const SeriesConst *)(ws + S.L.sc);
+    sp.series_of_cell = (const int *)(dw + W.ser);
+    sp.theta = (const double *)(dw + W.theta);
+    sp.X = (double *)(dw + W.X); sp.Y = (double *)(dw + W.Y);
+    sp.V = (double *)(dw + W.V); sp.J = (double *)(dw + W.J);
+    sp.lik = (double *)(dw + W.lik);
+    sp.status = (int *)(dw + W.st);
+    if (X || Y || V || J) HIPCHK(launch_smooth(sp, S.PP, S.QQ, A->stream));
+    HIPCHK(hipMemcpyAsync(pw + W.out_begin, dw + W.out_begin, W.out_bytes, hipMemcpyDeviceToHost,
+                          A->stream));
+    HIPCHK(hipStreamSynchronize(A->stream));
+    for (int i = 0; i < n_w; i++) {
+        if (liks_w) memcpy(liks_w + (size_t)i * niter, pw + W.liks + sizeof(double) * (size_t)i * niter, sizeof(double) * niter);
+        const size_t row = sizeof(double) * (size_t)i * T;
+        if (X) memcpy(X + (size_t)i * T, pw + W.X + row, sizeof(double) * T);
+        if (Y) memcpy(Y + (size_t)i * T, pw + W.Y + row, sizeof(double) * T);
+        if (V) memcpy(V + (size_t)i * T, pw + W.V + row, sizeof(double) * T);
+        if (J) memcpy(J + (size_t)i * T, pw + W.J + row, sizeof(double) * T);
+    }
+    return LDSR_OK;
+}
+
+// cut [0, n_cells) into n_devices contiguous slices and describe each
+static void make_slices(std::vector<Slice> &sl, int n_devices, const int *devices, int n_series,
+                        int T, int p, int q, const double *y, const double *u, const double *v,
+                        int shared_uv, const int *cell_offsets, const double *theta0, int niter,
+                        double tol, int algo, double *theta, double *lik, int *n_iter,
+                        int *status, double *liks, std::vector<int> &lo_of, std::vector<int> &s0_of) {
     const int n_cells = cell_offsets[n_series];
-    if (n_cells == 0) return LDSR_OK;
     const int P = 6 + p + q;
-    HIPCHK(hipSetDevice(device));
-    DevBufs B;
-    HostInputs H;
-    rc = upload_inputs(B, H, n_series, T, p, q, y, u, v, shared_uv);
-    if (rc) return rc;
-    double *d_theta0, *d_theta, *d_lik, *d_liks = nullptr;
-    int *d_n_iter, *d_status;
-    char *d_ws;
-    HIPCHK(B.alloc(&d_theta0, (size_t)n_cells * P));
-    HIPCHK(B.alloc(&d_theta, (size_t)n_cells * P));
-    HIPCHK(B.alloc(&d_lik, (size_t)n_cells));
-    HIPCHK(B.alloc(&d_n_iter, (size_t)n_cells));
-    HIPCHK(B.alloc(&d_status, (size_t)n_cells));
-    if (liks) HIPCHK(B.alloc(&d_liks, (size_t)n_cells * niter));
-    const size_t wsb = ldsr_em_workspace_bytes(n_series, T, p, q, n_cells, algo);
-    HIPCHK(B.alloc(&d_ws, wsb));
-    HIPCHK(hipMemcpy(d_theta0, theta0, sizeof(double) * (size_t)n_cells * P, hipMemcpyHostToDevice));
-    rc = ldsr_em_batch_device(device, nullptr, n_series, T, p, q, H.d_y, H.d_u, H.d_v, shared_uv,
-                              cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik, d_n_iter,
-                              d_status, d_liks, d_ws, wsb);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(nullptr));
-    HIPCHK(hipMemcpy(theta, d_theta, sizeof(double) * (size_t)n_cells * P, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(lik, d_lik, sizeof(double) * (size_t)n_cells, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n_iter, d_n_iter, sizeof(int) * (size_t)n_cells, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(status, d_status, sizeof(int) * (size_t)n_cells, hipMemcpyDeviceToHost));
-    if (liks)
-        HIPCHK(hipMemcpy(liks, d_liks, sizeof(double) * (size_t)n_cells * niter, hipMemcpyDeviceToHost));
+    sl.resize((size_t)n_devices);
+    lo_of.assign((size_t)n_devices + 1, n_cells);
+    s0_of.assign((size_t)n_devices, 0);
+    for (int d = 0; d < n_devices; d++) {
+        const int lo = (int)((long long)n_cells * d / n_devices);
+        const int hi = (int)((long long)n_cells * (d + 1) / n_devices);
+        lo_of[(size_t)d] = lo;
+        Slice &S = sl[(size_t)d];
+        S.device = devices[d];
+        S.T = T; S.p = p; S.q = q; S.shared_uv = shared_uv; S.niter = niter; S.tol = tol; S.algo = algo;
+        if (hi <= lo) {
+            S.n_series = 0;
+            S.off.assign(1, 0);
+            continue;
+        }
+        // series range [s0, s1) that owns cells [lo, hi), and the clipped local offsets
+        int s0 = 0;
+        while (cell_offsets[s0 + 1] <= lo) s0++;
+        int s1 = s0;
+        while (s1 < n_series && cell_offsets[s1] < hi) s1++;
+        s0_of[(size_t)d] = s0;
+        S.n_series = s1 - s0;
+        S.off.resize((size_t)(s1 - s0) + 1);
+        for (int s = s0; s <= s1; s++) {
+            int c = cell_offsets[s];
+            c = c < lo ? lo : (c > hi ? hi : c);
+            S.off[(size_t)(s - s0)] = c - lo;
+        }
+        const size_t uo = shared_uv ? 0 : (size_t)s0 * T * p, vo = shared_uv ? 0 : (size_t)s0 * T * q;
+        S.y = y + (size_t)s0 * T;
+        S.u = u ? u + uo : nullptr;
+        S.v = v ? v + vo : nullptr;
+        S.theta0 = theta0 + (size_t)lo * P;
+        S.theta = theta + (size_t)lo * P;
+        S.lik = lik + lo;
+        S.n_iter = n_iter + lo;
+        S.status = status + lo;
+        S.liks = liks ? liks + (size_t)lo * niter : nullptr;
+    }
+}
+
+// run phase 1 of every slice, one host thread per slice beyond the first
+static int run_slices(std::vector<Slice> &sl) {
+    const size_t n = sl.size();
+    std::vector<int> rcs(n, LDSR_OK);
+    std::vector<std::string> msgs(n);
+    auto work = [&](size_t d) {
+        rcs[d] = slice_run(sl[d]);
+        if (rcs[d]) msgs[d] = g_err;      // thread-local message of this worker
+    };
+    std::vector<std::thread> pool;
+    for (size_t d = 1; d < n; d++)
+        if (sl[d].n_series > 0) pool.emplace_back(work, d);
+    if (n > 0 && sl[0].n_series > 0) work(0);
+    for (auto &t : pool) t.join();
+    for (size_t d = 0; d < n; d++)
+        if (rcs[d]) return fail(rcs[d], "device " + std::to_string(sl[d].device) + ": " + msgs[d]);
     return LDSR_OK;
 }
 
-// Multi-GPU form of ldsr_em_batch: the cell grid is cut into contiguous slices, one host thread
-// per listed device runs its slice through ldsr_em_batch (cells are grouped by series, so a slice
-// is a contiguous range of series: plain pointer offsets, no gather).  No collective; results
-// land directly in the caller's arrays.  The same device may be listed more than once.
 extern "C" int ldsr_em_batch_multi(int n_devices, const int *devices, int n_series, int T, int p,
                                    int q, const double *y, const double *u, const double *v,
                                    int shared_uv, const int *cell_offsets, const double *theta0,
@@ -345,47 +767,149 @@ extern "C" int ldsr_em_batch_multi(int n_devices, const int *devices, int n_seri
     if (n_devices < 1 || !devices) return fail(LDSR_EINVAL, "n_devices must be >= 1");
     int rc = check_common(n_series, T, p, q, y, cell_offsets);
     if (rc) return rc;
-    if (niter < 2) return fail(LDSR_EINVAL, "niter must be >= 2 (the reference reads lik[1], src/EM.cpp:256)");
+    rc = check_em(niter, tol);
+    if (rc) return rc;
     if (!theta0 || !theta || !lik || !n_iter || !status) return fail(LDSR_EINVAL, "NULL pointer");
+    if (cell_offsets[n_series] == 0) return LDSR_OK;
+    std::vector<Slice> sl;
+    std::vector<int> lo_of, s0_of;
+    make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
+                niter, tol, algo, theta, lik, n_iter, status, liks, lo_of, s0_of);
+    return run_slices(sl);
+}
+
+extern "C" int ldsr_em_batch(int device, int n_series, int T, int p, int q, const double *y,
+                             const double *u, const double *v, int shared_uv,
+                             const int *cell_offsets, const double *theta0, int niter, double tol,
+                             int algo, double *theta, double *lik, int *n_iter, int *status,
+                             double *liks) {
+    return ldsr_em_batch_multi(1, &device, n_series, T, p, q, y, u, v, shared_uv, cell_offsets,
+                               theta0, niter, tol, algo, theta, lik, n_iter, status, liks);
+}
+
+extern "C" int ldsr_em_restart_grid(int n_devices, const int *devices, int n_series, int T, int p,
+                                    int q, const double *y, const double *u, const double *v,
+                                    int shared_uv, const int *cell_offsets, const double *theta0,
+                                    int niter, double tol, int algo, double *theta_all,
+                                    double *lik_all, int *n_iter_all, int *status_all, int *winner,
+                                    double *theta_w, double *lik_w, int *n_iter_w, double *liks_w,
+                                    double *X, double *Y, double *V, double *J) {
+    if (n_devices < 1 || !devices) return fail(LDSR_EINVAL, "n_devices must be >= 1");
+    int rc = check_common(n_series, T, p, q, y, cell_offsets);
+    if (rc) return rc;
+    rc = check_em(niter, tol);
+    if (rc) return rc;
+    if (!theta0 || !winner || !theta_w || !lik_w || !n_iter_w)
+        return fail(LDSR_EINVAL, "theta0, winner, theta_w, lik_w and n_iter_w must not be NULL");
     const int n_cells = cell_offsets[n_series];
     const int P = 6 + p + q;
-    std::vector<int> rcs((size_t)n_devices, LDSR_OK);
-    std::vector<std::string> msgs((size_t)n_devices);
-    std::vector<std::thread> pool;
-    for (int d = 0; d < n_devices; d++) {
-        const int lo = (int)((long long)n_cells * d / n_devices);
-        const int hi = (int)((long long)n_cells * (d + 1) / n_devices);
-        if (hi <= lo) continue;
-        pool.emplace_back([=, &rcs, &msgs]() {
-            // series range [s0, s1) that owns cells [lo, hi), and the clipped local offsets
-            int s0 = 0;
-            while (cell_offsets[s0 + 1] <= lo) s0++;
-            int s1 = s0;
-            while (s1 < n_series && cell_offsets[s1] < hi) s1++;
-            std::vector<int> off((size_t)(s1 - s0) + 1);
-            for (int s = s0; s <= s1; s++) {
-                int c = cell_offsets[s];
-                c = c < lo ? lo : (c > hi ? hi : c);
-                off[(size_t)(s - s0)] = c - lo;
-            }
-            const size_t uo = shared_uv ? 0 : (size_t)s0 * T * p, vo = shared_uv ? 0 : (size_t)s0 * T * q;
-            const int r = ldsr_em_batch(devices[d], s1 - s0, T, p, q, y + (size_t)s0 * T,
-                                        u ? u + uo : nullptr, v ? v + vo : nullptr, shared_uv,
-                                        off.data(), theta0 + (size_t)lo * P, niter, tol, algo,
-                                        theta + (size_t)lo * P, lik + lo, n_iter + lo, status + lo,
-                                        liks ? liks + (size_t)lo * niter : nullptr);
-            rcs[(size_t)d] = r;
-            if (r) msgs[(size_t)d] = ldsr_last_error();   // thread-local message of this worker
-        });
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    // per-cell results the caller did not ask for live in temporaries (selection needs them)
+    std::vector<double> t_theta, t_lik;
+    std::vector<int> t_nit, t_st;
+    if (!theta_all) { t_theta.resize((size_t)n_cells * P + 1); theta_all = t_theta.data(); }
+    if (!lik_all) { t_lik.resize((size_t)n_cells + 1); lik_all = t_lik.data(); }
+    if (!n_iter_all) { t_nit.resize((size_t)n_cells + 1); n_iter_all = t_nit.data(); }
+    if (!status_all) { t_st.resize((size_t)n_cells + 1); status_all = t_st.data(); }
+
+    if (n_devices > n_cells) n_devices = n_cells > 0 ? n_cells : 1;
+    std::vector<Slice> sl;
+    std::vector<int> lo_of, s0_of;
+    make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
+                niter, tol, algo, theta_all, lik_all, n_iter_all, status_all, nullptr, lo_of, s0_of);
+    for (Slice &S : sl) S.max_winners = S.n_series;
+    if (n_cells > 0) {
+        rc = run_slices(sl);
+        if (rc) return rc;
     }
-    for (auto &t : pool) t.join();
-    for (int d = 0; d < n_devices; d++)
-        if (rcs[(size_t)d])
-            return fail(rcs[(size_t)d], "device " + std::to_string(devices[d]) + ": " + msgs[(size_t)d]);
+    // selection (R/LDS_reconstruction.R:50-58), per series over its restarts
+    for (int s = 0; s < n_series; s++) {
+        const int a = cell_offsets[s], b = cell_offsets[s + 1];
+        const int k = ldsr_select_restart(b - a, lik_all + a, theta_all + (size_t)a * P, p, q);
+        winner[s] = k < 0 ? -1 : a + k;
+        if (k < 0) {
+            for (int j = 0; j < P; j++) theta_w[(size_t)s * P + j] = nan;
+            lik_w[s] = nan;
+            n_iter_w[s] = 0;
+        } else {
+            memcpy(theta_w + (size_t)s * P, theta_all + (size_t)(a + k) * P, sizeof(double) * P);
+            lik_w[s] = lik_all[a + k];
+            n_iter_w[s] = n_iter_all[a + k];
+        }
+        if (k < 0) {
+            if (liks_w) for (int i = 0; i < niter; i++) liks_w[(size_t)s * niter + i] = nan;
+            double *rows[4] = {X, Y, V, J};
+            for (double *r : rows)
+                if (r) for (int t = 0; t < T; t++) r[(size_t)s * T + t] = nan;
+        }
+    }
+    if (!liks_w && !X && !Y && !V && !J) return LDSR_OK;
+    // phase 2 on the slice that owns each winner
+    for (size_t d = 0; d < sl.size(); d++) {
+        Slice &S = sl[d];
+        if (S.n_series == 0) continue;
+        const int lo = lo_of[d], hi = lo_of[d + 1], s0 = s0_of[d];
+        std::vector<int> ws_, wc_, gs_;
+        for (int s = s0; s < s0 + S.n_series; s++)
+            if (winner[s] >= lo && winner[s] < hi) {
+                ws_.push_back(s - s0);
+                wc_.push_back(winner[s] - lo);
+                gs_.push_back(s);
+            }
+        const int n_w = (int)ws_.size();
+        if (!n_w) continue;
+        std::vector<double> b_liks, b_X, b_Y, b_V, b_J;
+        if (liks_w) b_liks.resize((size_t)n_w * niter);
+        if (X) b_X.resize((size_t)n_w * T);
+        if (Y) b_Y.resize((size_t)n_w * T);
+        if (V) b_V.resize((size_t)n_w * T);
+        if (J) b_J.resize((size_t)n_w * T);
+        rc = slice_fit_winners(S, n_w, ws_.data(), wc_.data(), liks_w ? b_liks.data() : nullptr,
+                               X ? b_X.data() : nullptr, Y ? b_Y.data() : nullptr,
+                               V ? b_V.data() : nullptr, J ? b_J.data() : nullptr);
+        if (rc) return rc;
+        for (int i = 0; i < n_w; i++) {
+            const size_t s = (size_t)gs_[(size_t)i];
+            if (liks_w) memcpy(liks_w + s * niter, b_liks.data() + (size_t)i * niter, sizeof(double) * niter);
+            if (X) memcpy(X + s * T, b_X.data() + (size_t)i * T, sizeof(double) * T);
+            if (Y) memcpy(Y + s * T, b_Y.data() + (size_t)i * T, sizeof(double) * T);
+            if (V) memcpy(V + s * T, b_V.data() + (size_t)i * T, sizeof(double) * T);
+            if (J) memcpy(J + s * T, b_J.data() + (size_t)i * T, sizeof(double) * T);
+        }
+    }
     return LDSR_OK;
 }
 
-// Shared driver of the smoother / propagate / mstep host entry points.
+extern "C" int ldsr_em_restart_groups(int n_devices, const int *devices, int n_groups,
+                                      ldsr_group *groups, int niter, double tol, int algo) {
+    if (n_devices < 1 || !devices) return fail(LDSR_EINVAL, "n_devices must be >= 1");
+    if (n_groups < 0 || (n_groups > 0 && !groups)) return fail(LDSR_EINVAL, "groups must not be NULL");
+    std::vector<std::string> msgs((size_t)n_groups);
+    auto work = [&](int g) {
+        ldsr_group &G = groups[g];
+        // rotate the device list so that concurrent groups start on different GPUs
+        std::vector<int> devs((size_t)n_devices);
+        for (int d = 0; d < n_devices; d++) devs[(size_t)d] = devices[(g + d) % n_devices];
+        G.rc = ldsr_em_restart_grid(n_devices, devs.data(), G.n_series, G.T, G.p, G.q, G.y, G.u, G.v,
+                                    G.shared_uv, G.cell_offsets, G.theta0, niter, tol, algo,
+                                    G.theta_all, G.lik_all, G.n_iter_all, G.status_all, G.winner,
+                                    G.theta_w, G.lik_w, G.n_iter_w, G.liks_w, G.X, G.Y, G.V, G.J);
+        if (G.rc) msgs[(size_t)g] = g_err;
+    };
+    // a bounded pool: at most 8 groups in flight (each holds one arena per device)
+    const int n_workers = std::min(n_groups, 8);
+    std::vector<std::thread> pool;
+    for (int w = 0; w < n_workers; w++)
+        pool.emplace_back([&, w]() {
+            for (int g = w; g < n_groups; g += n_workers) work(g);
+        });
+    for (auto &t : pool) t.join();
+    for (int g = 0; g < n_groups; g++)
+        if (groups[g].rc) return fail(groups[g].rc, "group " + std::to_string(g) + ": " + msgs[(size_t)g]);
+    return LDSR_OK;
+}
+
+// ---- smoother / propagate / mstep / penalized likelihood host entry points ---------------------
 // mode: 0 smoother, 1 propagate, 2 mstep, 3 penalized likelihood (smoother, scalar output only)
 static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int q, const double *y,
                           const double *u, const double *v, int shared_uv,
@@ -396,23 +920,51 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     if (rc) return rc;
     const int n_cells = cell_offsets[n_series];
     if (n_cells == 0) return LDSR_OK;
+    if (mode == 2 && (!X || !V || !J || !theta_out)) return fail(LDSR_EINVAL, "mstep needs X, V, J and theta");
+    if (mode != 2 && (!theta_in || !lik)) return fail(LDSR_EINVAL, "theta and lik must not be NULL");
     const int P = 6 + p + q;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
-    HIPCHK(hipSetDevice(device));
-    DevBufs B;
-    HostInputs H;
-    rc = upload_inputs(B, H, n_series, T, p, q, y, u, v, shared_uv);
+    const size_t nuv = shared_uv ? 1 : (size_t)n_series;
+    const size_t nT = (size_t)n_cells * T;
+    const bool scalar_only = mode == 3;     // only [n_cells] scalars leave the device
+    ArenaLease lease;
+    rc = arena_acquire(device, &lease.a);
     if (rc) return rc;
+    Arena *A = lease.a;
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, LDSR_ALGO_SCAN, 64);
-    char *ws;
-    HIPCHK(B.alloc(&ws, L.total));
-    rc = prepare_series(nullptr, n_series, T, p, q, PP, QQ, H.d_y, H.d_u, H.d_v, shared_uv, ws, L);
+    Carver c;
+    const size_t o_y = c.take(sizeof(double) * (size_t)n_series * T);
+    const size_t o_u = c.take(u ? sizeof(double) * nuv * T * p : 0);
+    const size_t o_v = c.take(v ? sizeof(double) * nuv * T * q : 0);
+    const size_t o_th = c.take(sizeof(double) * (size_t)n_cells * P);
+    const size_t o_soc = c.take(sizeof(int) * (size_t)n_cells);
+    const size_t in_bytes = c.o;
+    const size_t o_lik = c.take(sizeof(double) * (size_t)n_cells);
+    const size_t o_pen = c.take(sizeof(double) * (size_t)n_cells);
+    const size_t o_st = c.take(sizeof(int) * (size_t)n_cells);
+    const size_t o_tho = c.take(sizeof(double) * (size_t)n_cells * P);
+    const size_t small_out = c.o - o_lik;
+    const size_t o_X = c.take(sizeof(double) * nT);     // X / V double as the filtered-state strip
+    const size_t o_V = c.take(sizeof(double) * nT);
+    const size_t o_Y = c.take(scalar_only ? 0 : sizeof(double) * nT);
+    const size_t o_J = c.take(scalar_only ? 0 : sizeof(double) * nT);
+    const size_t o_ws = c.take(L.total);
+    rc = arena_reserve(A, c.o, in_bytes + align256(small_out));
     if (rc) return rc;
-    std::vector<int> soc((size_t)n_cells);
+    char *dev = A->dev, *pin = A->pin;
+    memcpy(pin + o_y, y, sizeof(double) * (size_t)n_series * T);
+    if (u) memcpy(pin + o_u, u, sizeof(double) * nuv * T * p);
+    if (v) memcpy(pin + o_v, v, sizeof(double) * nuv * T * q);
+    if (theta_in) memcpy(pin + o_th, theta_in, sizeof(double) * (size_t)n_cells * P);
+    int *soc = (int *)(pin + o_soc);
     for (int s = 0; s < n_series; s++)
-        for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c++) soc[c] = s;
-    int *d_soc = (int *)(ws + L.soc);
-    HIPCHK(hipMemcpy(d_soc, soc.data(), sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice));
+        for (int cc = cell_offsets[s]; cc < cell_offsets[s + 1]; cc++) soc[cc] = s;
+    HIPCHK(hipMemcpyAsync(dev, pin, in_bytes, hipMemcpyHostToDevice, A->stream));
+    char *ws = dev + o_ws;
+    rc = prepare_series(A->stream, n_series, T, p, q, PP, QQ, (const double *)(dev + o_y),
+                        u ? (const double *)(dev + o_u) : nullptr,
+                        v ? (const double *)(dev + o_v) : nullptr, shared_uv, ws, L);
+    if (rc) return rc;
 
     SmoothParams sp;
     memset(&sp, 0, sizeof(sp));
@@ -425,50 +977,40 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     sp.u_stride = shared_uv ? 0 : (long)T * PP;
     sp.v_stride = shared_uv ? 0 : (long)T * QQ;
     sp.sc = (const SeriesConst *)(ws + L.sc);
-    sp.series_of_cell = d_soc;
-    const size_t nT = (size_t)n_cells * T;
-    double *d_X, *d_Y, *d_V, *d_J, *d_lik, *d_theta;
-    int *d_status;
-    HIPCHK(B.alloc(&d_X, nT));
-    HIPCHK(B.alloc(&d_Y, nT));
-    HIPCHK(B.alloc(&d_V, nT));
-    HIPCHK(B.alloc(&d_J, nT));
-    HIPCHK(B.alloc(&d_lik, (size_t)n_cells));
-    HIPCHK(B.alloc(&d_theta, (size_t)n_cells * P));
-    HIPCHK(B.alloc(&d_status, (size_t)n_cells));
-    sp.X = d_X; sp.Y = d_Y; sp.V = d_V; sp.J = d_J; sp.lik = d_lik;
-    sp.status = d_status;
+    sp.series_of_cell = (const int *)(dev + o_soc);
+    sp.X = (double *)(dev + o_X); sp.Y = (double *)(dev + o_Y);
+    sp.V = (double *)(dev + o_V); sp.J = (double *)(dev + o_J);
+    sp.lik = (double *)(dev + o_lik);
+    sp.status = (int *)(dev + o_st);
+    char *pout = pin + in_bytes;
     if (mode == 2) {
-        if (!X || !V || !J || !theta_out) return fail(LDSR_EINVAL, "mstep needs X, V, J and theta");
-        HIPCHK(hipMemcpy(d_X, X, sizeof(double) * nT, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_V, V, sizeof(double) * nT, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_J, J, sizeof(double) * nT, hipMemcpyHostToDevice));
-        sp.theta_out = d_theta;
-        HIPCHK(launch_mstep(sp, PP, QQ, nullptr));
-        HIPCHK(hipStreamSynchronize(nullptr));
-        HIPCHK(hipMemcpy(theta_out, d_theta, sizeof(double) * (size_t)n_cells * P, hipMemcpyDeviceToHost));
-        if (status) HIPCHK(hipMemcpy(status, d_status, sizeof(int) * (size_t)n_cells, hipMemcpyDeviceToHost));
+        // the fit arrives from the caller: X, V, J rows straight into the device arrays
+        HIPCHK(hipMemcpyAsync(dev + o_X, X, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
+        HIPCHK(hipMemcpyAsync(dev + o_V, V, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
+        HIPCHK(hipMemcpyAsync(dev + o_J, J, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
+        sp.theta_out = (double *)(dev + o_tho);
+        HIPCHK(launch_mstep(sp, PP, QQ, A->stream));
+        HIPCHK(hipMemcpyAsync(pout, dev + o_lik, small_out, hipMemcpyDeviceToHost, A->stream));
+        HIPCHK(hipStreamSynchronize(A->stream));
+        memcpy(theta_out, pout + (o_tho - o_lik), sizeof(double) * (size_t)n_cells * P);
+        if (status) memcpy(status, pout + (o_st - o_lik), sizeof(int) * (size_t)n_cells);
         return LDSR_OK;
     }
-    if (!theta_in || !lik) return fail(LDSR_EINVAL, "theta and lik must not be NULL");
-    HIPCHK(hipMemcpy(d_theta, theta_in, sizeof(double) * (size_t)n_cells * P, hipMemcpyHostToDevice));
-    sp.theta = d_theta;
-    double *d_pen = nullptr;
-    if (mode == 3) {
-        HIPCHK(B.alloc(&d_pen, (size_t)n_cells));
-        sp.pen = d_pen;
-    }
-    HIPCHK(launch_smooth(sp, PP, QQ, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
-    if (mode == 3) {
-        HIPCHK(hipMemcpy(lik, d_pen, sizeof(double) * (size_t)n_cells, hipMemcpyDeviceToHost));
+    sp.theta = (const double *)(dev + o_th);
+    sp.pen = scalar_only ? (double *)(dev + o_pen) : nullptr;
+    sp.scalar_only = scalar_only;
+    HIPCHK(launch_smooth(sp, PP, QQ, A->stream));
+    HIPCHK(hipMemcpyAsync(pout, dev + o_lik, small_out, hipMemcpyDeviceToHost, A->stream));
+    HIPCHK(hipStreamSynchronize(A->stream));
+    if (scalar_only) {
+        memcpy(lik, pout + (o_pen - o_lik), sizeof(double) * (size_t)n_cells);
         return LDSR_OK;
     }
-    if (X) HIPCHK(hipMemcpy(X, d_X, sizeof(double) * nT, hipMemcpyDeviceToHost));
-    if (Y) HIPCHK(hipMemcpy(Y, d_Y, sizeof(double) * nT, hipMemcpyDeviceToHost));
-    if (V) HIPCHK(hipMemcpy(V, d_V, sizeof(double) * nT, hipMemcpyDeviceToHost));
-    if (J && mode == 0) HIPCHK(hipMemcpy(J, d_J, sizeof(double) * nT, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(lik, d_lik, sizeof(double) * (size_t)n_cells, hipMemcpyDeviceToHost));
+    memcpy(lik, pout, sizeof(double) * (size_t)n_cells);
+    if (X) HIPCHK(hipMemcpy(X, dev + o_X, sizeof(double) * nT, hipMemcpyDeviceToHost));
+    if (Y) HIPCHK(hipMemcpy(Y, dev + o_Y, sizeof(double) * nT, hipMemcpyDeviceToHost));
+    if (V) HIPCHK(hipMemcpy(V, dev + o_V, sizeof(double) * nT, hipMemcpyDeviceToHost));
+    if (J && mode == 0) HIPCHK(hipMemcpy(J, dev + o_J, sizeof(double) * nT, hipMemcpyDeviceToHost));
     return LDSR_OK;
 }
 

@@ -159,6 +159,7 @@ __device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, Q
 // Kernel argument block shared by the EM kernels.
 struct EmParams {
     int T, p, q, has_u, has_v, niter, n_cells;
+    int liks_nanfill;        // pad liks[cell][n_iter..niter) with NaN (the batch ABI); 0 = leave as is
     double tol;
     const double *yp;        // [n_series][T]       NaN = missing
     const double *yz;        // [n_series][T]       same with 0 where missing (scan kernel, global-image variant)

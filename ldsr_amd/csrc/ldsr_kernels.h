@@ -25,16 +25,34 @@ struct SmoothParams {
     int *status;
     double *pen;          // smoother: lik - lambda * ssq (penalized_likelihood), may be null
     double lambda;
+    int scalar_only;      // only lik / pen leave the kernel: Y and J are not written
+};
+
+// Winner extraction of the restart-grid entry: row i of the *_w arrays = cell[i] of the batch.
+struct GatherParams {
+    int n_w, P, niter;
+    const int *cell;          // [n_w] cell index of each winner
+    const double *theta;      // [n_cells][P] fitted
+    const double *theta0;     // [n_cells][P] initial
+    const int *n_iter;        // [n_cells]
+    const double *liks;       // [n_cells][niter] traces (entries beyond n_iter undefined), or null
+    double *theta_w, *theta0_w;   // [n_w][P]
+    double *liks_w;           // [n_w][niter], NaN padded (untouched when liks is null)
 };
 
 static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16; }
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream);
 hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);
-hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, int waves_per_block,
-                          bool queue, hipStream_t stream);
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
+                          hipStream_t stream);
 bool em_scan_global_image(int T, int PP, int QQ);   // series image too large for LDS: read from L2
+bool em_scan_queue_only(int T, int PP, int QQ);     // shapes compiled with the work-queue schedule only
 bool em_scan_supported(int T, int PP, int QQ);
-int em_scan_waves_per_block(int T, int PP, int QQ);
+int em_scan_cells_per_block(int T, int PP, int QQ);
+// kernel names as rocprofv3 prints them (ldsr_em_plan)
+void em_scan_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len);
+void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);
+hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);
 hipError_t launch_mstep(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);

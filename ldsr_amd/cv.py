@@ -78,7 +78,7 @@ def calculate_metrics(sim, obs, z, norm_fun=np.nanmean):
 
 
 def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed=1, r_seed=None,
-            mu=0.0, device=0, engine=None):
+            mu=0.0, device=0, devices=None, engine=None):
     """All folds x restarts in one launch.
 
     y [T] (centred, NaN outside the instrumental period), u [p,T] / v [q,T] or None,
@@ -99,11 +99,19 @@ def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed
         th0 = make_init_packed_r(p, q, F * num_restarts, r_seed)   # fresh make_init per fold (:275)
     else:
         th0 = make_init_packed(p, q, F * num_restarts, seed=seed)
-    em = engine["em_batch"] if engine else api.em_batch
-    sm = engine["smooth_batch"] if engine else api.smooth_batch
-    sel = engine["select"] if engine else api.select_restart
-    kw = {} if engine else {"device": device}
-    r = em(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol, **kw)
+    if engine is None:
+        # product path: folds x restarts, selection and the winners' fits in ONE library call
+        r = api.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol,
+                                devices=(device,) if devices is None else devices)
+        if np.any(r["winner"] < 0):
+            raise RuntimeError("fold %d: no restart produced a finite likelihood"
+                               % int(np.nonzero(r["winner"] < 0)[0][0]))
+        Ycv = r["Y"][:, inst_period] + mu                    # fit$Y[instPeriod] + mu  (:283)
+        return {"Ycv": Ycv, "theta": r["theta"], "lik": r["lik"], "winner": r["winner"].astype(np.int64),
+                "Z": Z, "all": r["all"]}
+    # test hook: the same host logic on another engine (the CPU oracle checks it)
+    em, sm, sel = engine["em_batch"], engine["smooth_batch"], engine["select"]
+    r = em(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol)
     winner = np.full(F, -1, dtype=np.int64)
     for f in range(F):
         a, b = off[f], off[f + 1]
@@ -112,7 +120,7 @@ def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed
             raise RuntimeError("fold %d: no restart produced a finite likelihood" % f)
         winner[f] = a + k
     th_w = r["theta"][winner]
-    fit = sm(Y, u, v, th_w, cell_offsets=np.arange(F + 1, dtype=np.int32), **kw)
+    fit = sm(Y, u, v, th_w, cell_offsets=np.arange(F + 1, dtype=np.int32))
     Ycv = fit["Y"][:, inst_period] + mu                      # fit$Y[instPeriod] + mu  (:283)
     return {"Ycv": Ycv, "theta": th_w, "lik": r["lik"][winner], "winner": winner, "Z": Z,
             "all": r}

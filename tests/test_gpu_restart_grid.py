@@ -1,0 +1,218 @@
+"""GPU tests of the one-call restart entry points (ldsr_em_restart_grid / _groups) and of the
+asynchronous device entry.  The per-cell numerics are covered by test_gpu_parity.py; here the
+new host/device plumbing is checked against the batch entry + host logic (bit-identical) and
+against the oracle where a number is compared."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import parity_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import ldsr_amd
+    from ldsr_amd import _lib
+    assert _lib.lib().ldsr_device_count() >= 1, "no GPU visible"
+    return ldsr_amd
+
+
+def _cv_like(T=300, p=2, q=3, F=5, R=12, seed=11):
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(T, p, q, series_id=31, mask="paleo", n_tail=60)
+    Y = np.repeat(y[None], F, axis=0)
+    for f in range(F):
+        Y[f, T - 60 + 9 * f:T - 60 + 9 * f + 7] = np.nan
+    off = (np.arange(F + 1) * R).astype(np.int32)
+    if R > 6:
+        off[2] -= 5      # ragged: folds need not have equal restart counts
+    th0 = synth.make_init_packed(p, q, int(off[-1]), seed=seed)
+    return Y, u, v, off, th0, p, q
+
+
+def _reference_by_parts(eng, Y, u, v, off, th0, p, q, niter, tol):
+    """The same result assembled from the batch entry + host selection + smoother call."""
+    b = eng.em_batch(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol, return_liks=True)
+    S = len(off) - 1
+    win = np.array([off[s] + eng.select_restart(b["lik"][off[s]:off[s + 1]],
+                                                b["theta"][off[s]:off[s + 1]], p, q)
+                    for s in range(S)])
+    fit = eng.smooth_batch(Y, u, v, b["theta"][win], cell_offsets=np.arange(S + 1, dtype=np.int32))
+    return b, win, fit
+
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0, 0)])
+@pytest.mark.parametrize("tol", [1e-5, 0.0])
+def test_restart_grid_equals_batch_plus_host_logic(eng, devices, tol):
+    Y, u, v, off, th0, p, q = _cv_like()
+    niter = 60
+    r = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=niter, tol=tol, devices=devices)
+    b, win, fit = _reference_by_parts(eng, Y, u, v, off, th0, p, q, niter, tol)
+    for k in ("theta", "lik", "n_iter", "status"):
+        assert np.array_equal(r["all"][k], b[k], equal_nan=True), k
+    assert np.array_equal(r["winner"], win)
+    assert np.array_equal(r["theta"], b["theta"][win])
+    assert np.array_equal(r["lik"], b["lik"][win])
+    assert np.array_equal(r["n_iter"], b["n_iter"][win])
+    assert np.array_equal(r["liks"], b["liks"][win], equal_nan=True)
+    for s in range(len(win)):                     # trace: n_iter finite entries, then NaN
+        assert np.all(np.isfinite(r["liks"][s, :r["n_iter"][s]]))
+        assert np.all(np.isnan(r["liks"][s, r["n_iter"][s]:]))
+        assert r["liks"][s, r["n_iter"][s] - 1] == r["lik"][s]
+    for k in "XYVJ":
+        assert np.array_equal(r[k], fit[k]), k
+    assert parity_close(fit["lik"], r["lik"], 1e-9, 1e-12)   # the fit is the winner's last E-step
+
+
+def test_restart_grid_without_per_cell_outputs_and_optional_rows(eng):
+    Y, u, v, off, th0, p, q = _cv_like(F=3, R=6)
+    full = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=40, tol=1e-5)
+    slim = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=40, tol=1e-5, return_all=False)
+    assert "all" not in slim
+    for k in ("winner", "theta", "lik", "n_iter", "X", "Y", "V", "J"):
+        assert np.array_equal(full[k], slim[k]), k
+    assert np.array_equal(full["liks"], slim["liks"], equal_nan=True)
+
+
+def test_restart_grid_winner_rerun_path_is_identical(eng, monkeypatch):
+    """Traces too large to keep on the device (cap forced to 0): the winners are re-run alone."""
+    Y, u, v, off, th0, p, q = _cv_like()
+    a = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=80, tol=1e-5)
+    monkeypatch.setenv("LDSR_LIKS_TRACE_MAX_BYTES", "0")
+    b = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=80, tol=1e-5)
+    for k in ("winner", "theta", "lik", "n_iter", "X", "Y", "V", "J"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["liks"], b["liks"], equal_nan=True)
+
+
+def test_restart_grid_series_without_a_selectable_winner(eng):
+    """A fold whose restarts all end with NaN likelihoods has no winner (R's which.max on
+    all-NA gives integer(0)): winner -1 and NaN rows, the other folds are unaffected."""
+    Y, u, v, off, th0, p, q = _cv_like(F=3, R=4)
+    th0 = th0.copy()
+    th0[off[1]:off[2], 3 + p + q] = -5.0         # R < 0 in every restart of fold 1: log(Sigma) = NaN
+    r = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=3, tol=0.0)
+    assert np.all(np.isnan(r["all"]["lik"][off[1]:off[2]]))
+    assert r["winner"][1] == -1 and r["winner"][0] >= 0 and r["winner"][2] >= 0
+    assert np.all(np.isnan(r["theta"][1])) and np.all(np.isnan(r["X"][1])) and np.all(np.isnan(r["liks"][1]))
+    assert np.all(np.isfinite(r["X"][[0, 2]]))
+
+
+def test_lds_em_restart_matches_oracle_winner(eng, p1case):
+    from oracle import oracle as O
+    from ldsr_amd import synth
+    c = p1case
+    th0 = synth.make_init_packed(7, 7, 24, seed=5)
+    init = [eng.unpack_theta(t, 7, 7) for t in th0]
+    win = eng.LDS_EM_restart(c["y"], c["u"], c["v"], init, niter=200, tol=1e-5)
+    ref = [O.lds_em(c["y"], c["u"], c["v"], t, 200, 1e-5) for t in th0]
+    k = O.select(np.array([r["lik"] for r in ref]), np.array([r["theta"][8] for r in ref]))
+    assert win["all"]["selected"] == k
+    assert len(win["liks"]) == len(ref[k]["liks"])
+    assert parity_close(win["liks"], ref[k]["liks"], 1e-6, 1e-9)
+    assert parity_close(win["lik"], ref[k]["lik"], 1e-6, 1e-9)
+    for name in "XYVJ":
+        assert parity_close(win["fit"][name][0], ref[k]["fit"][name], 1e-6, 1e-9), name
+    assert win["fit"]["X"].shape == (1, 85)
+    assert win["init"] is init[k]
+
+
+def test_heterogeneous_ensemble_groups(eng, p1case):
+    """tests/testthat/test-ensemble.R:4-18: ensemble members with different numbers of rows in
+    u and v; every member must equal its own single-member run."""
+    from ldsr_amd import synth
+    c = p1case
+    members = [(c["u"][:3], c["v"][:2]), (c["u"][1:3], c["v"][:5]), (None, c["v"][:4]),
+               (c["u"], c["v"])]
+    inits = [synth.make_init_packed(1 if u is None else u.shape[0], v.shape[0], 10 + 3 * i, seed=40 + i)
+             for i, (u, v) in enumerate(members)]
+    res = eng.ensemble_restart(c["y"], members, inits, niter=50, tol=1e-5)
+    assert len(res) == len(members)
+    for (u, v), th0, r in zip(members, inits, res):
+        solo = eng.em_restart_grid(c["y"], u, v, th0, niter=50, tol=1e-5)
+        for k in ("winner", "theta", "lik", "n_iter", "X", "Y", "V", "J"):
+            assert np.array_equal(r[k], solo[k]), k
+        assert np.array_equal(r["all"]["theta"], solo["all"]["theta"])
+
+
+def _device_call(L, stream_ptr, S, T, p, q, d, off_c, niter, tol, ws_ptr, wsb):
+    from ldsr_amd import _lib
+    _lib.check(L.ldsr_em_batch_device(
+        0, C.c_void_p(stream_ptr), S, T, p, q, d["y"].data_ptr(), d["u"].data_ptr(),
+        d["v"].data_ptr(), 1, off_c, d["th0"].data_ptr(), niter, tol, 0, d["th"].data_ptr(),
+        d["lik"].data_ptr(), d["nit"].data_ptr(), d["st"].data_ptr(), None, C.c_void_p(ws_ptr), wsb))
+
+
+def test_device_entry_is_asynchronous_and_keeps_no_host_pointer(eng):
+    """ldsr_em_batch_device on a non-blocking stream: the host block table / cell_offsets are
+    clobbered and freed right after each call returns, calls are issued back to back without any
+    synchronisation, and the results must equal the synchronous host-pointer entry."""
+    import torch
+    from ldsr_amd import _lib
+    L = _lib.lib()
+    Y, u, v, off, th0, p, q = _cv_like(T=400, F=6, R=20)
+    S, T = Y.shape
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)          # non-blocking w.r.t. the null stream
+    ref = eng.em_batch(Y, u, v, th0, cell_offsets=off, niter=50, tol=1e-5)
+    d = {"y": torch.from_numpy(Y).to(dev), "u": torch.from_numpy(np.ascontiguousarray(u.T)).to(dev),
+         "v": torch.from_numpy(np.ascontiguousarray(v.T)).to(dev), "th0": torch.from_numpy(th0).to(dev)}
+    n = th0.shape[0]
+    wsb = L.ldsr_em_workspace_bytes(S, T, p, q, n, 0)
+    outs = []
+    torch.cuda.synchronize(dev)
+    for rep in range(20):                           # wraps the 16-slot staging ring
+        o = {"th": torch.empty_like(d["th0"]), "lik": torch.empty(n, dtype=torch.float64, device=dev),
+             "nit": torch.empty(n, dtype=torch.int32, device=dev),
+             "st": torch.empty(n, dtype=torch.int32, device=dev),
+             "ws": torch.empty(wsb + 256, dtype=torch.uint8, device=dev)}
+        off_c = (C.c_int * (S + 1))(*[int(x) for x in off])
+        _device_call(L, stream.cuda_stream, S, T, p, q, {**d, **o}, off_c, 50, 1e-5,
+                     (o["ws"].data_ptr() + 255) & ~255, wsb)
+        for i in range(S + 1):                      # clobber, then drop, the host table
+            off_c[i] = -12345
+        del off_c
+        outs.append(o)
+    stream.synchronize()
+    for o in outs:
+        assert np.array_equal(o["nit"].cpu().numpy(), ref["n_iter"])
+        assert np.array_equal(o["th"].cpu().numpy(), ref["theta"])
+        assert np.array_equal(o["lik"].cpu().numpy(), ref["lik"])
+
+
+def test_queue_is_reset_between_launches_sharing_a_workspace(eng):
+    """Regression for the work-queue schedule (tol > 0): the per-series queue heads live in the
+    workspace and are reset by series_prep of every launch, so back-to-back launches on ONE
+    workspace -- with different grids -- each process every cell exactly once."""
+    import torch
+    from ldsr_amd import _lib
+    L = _lib.lib()
+    Y, u, v, off, th0, p, q = _cv_like(T=400, F=6, R=20)
+    S, T = Y.shape
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    n = th0.shape[0]
+    d = {"y": torch.from_numpy(Y).to(dev), "u": torch.from_numpy(np.ascontiguousarray(u.T)).to(dev),
+         "v": torch.from_numpy(np.ascontiguousarray(v.T)).to(dev), "th0": torch.from_numpy(th0).to(dev)}
+    wsb = L.ldsr_em_workspace_bytes(S, T, p, q, n, 0)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) & ~255
+    off2 = off.copy()
+    off2[1:] -= off[1] // 2                          # a smaller first series: another grid
+    th0b = th0[off[1] // 2:]
+    for offs, t0 in ((off, th0), (off2, th0b), (off, th0)):
+        m = t0.shape[0]
+        o = {"th0": torch.from_numpy(np.ascontiguousarray(t0)).to(dev),
+             "th": torch.full((m, t0.shape[1]), np.nan, dtype=torch.float64, device=dev),
+             "lik": torch.full((m,), np.nan, dtype=torch.float64, device=dev),
+             "nit": torch.full((m,), -1, dtype=torch.int32, device=dev),
+             "st": torch.full((m,), -1, dtype=torch.int32, device=dev)}
+        off_c = (C.c_int * (S + 1))(*[int(x) for x in offs])
+        _device_call(L, stream.cuda_stream, S, T, p, q, {**d, **o}, off_c, 40, 1e-5, ws_ptr, wsb)
+        torch.cuda.synchronize(dev)
+        ref = eng.em_batch(Y, u, v, t0, cell_offsets=offs, niter=40, tol=1e-5)
+        assert np.array_equal(o["nit"].cpu().numpy(), ref["n_iter"])      # no cell skipped (-1) or redone
+        assert np.array_equal(o["th"].cpu().numpy(), ref["theta"])
