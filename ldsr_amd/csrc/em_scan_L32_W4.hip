@@ -1,0 +1,3 @@
+#define SCAN_L 32
+#define SCAN_W 4
+#include "em_scan_launch.inc"

@@ -1,11 +1,14 @@
-// em_scan_impl.h -- wave-per-cell, parallel-in-time EM kernel (the fast path: T <= 2048, p, q <= 8).
+// em_scan_impl.h -- wave-per-cell, parallel-in-time EM kernel (the fast path: T <= 8192, p, q <= 8).
 //
-// One 64-lane wavefront owns one (series, restart) cell for the whole EM loop.  nl = ceil(T/L)
-// lanes are active; lane l owns L (the first rp lanes) or L-1 consecutive time steps, so only
-// the last step of a chunk is predicated.  All per-step state lives in that lane's registers
-// and nothing but the final theta / lik / n_iter / status ever goes to HBM.  The series
-// (y, u, v) is staged once per workgroup into LDS in a chunk-transposed layout [j][lane] so
-// that the 64 lanes of a wave read consecutive 8-byte words (conflict-free ds_read_b64).
+// W (1, 2 or 4) 64-lane wavefronts own one (series, restart) cell for the whole EM loop: a cell
+// is spread over NL = 64 W "virtual lanes".  nl = ceil(T/L) of them are active; virtual lane l
+// owns L (the first rp lanes) or L-1 consecutive time steps, so only the last step of a chunk is
+// predicated.  All per-step state lives in that lane's registers and nothing but the final theta
+// / lik / n_iter / status ever goes to HBM.  The series (y, u, v) comes as a chunk-transposed
+// image [j][k][virtual lane] built once per launch by series_prep_kernel; the kernel copies it
+// into LDS (flat coalesced copy; the 64 lanes of a wave then read consecutive 8-byte words:
+// conflict-free ds_read_b64) or, when it exceeds the 160 KiB of a CU (GIMG), reads the very same
+// layout straight from global memory (coalesced 512-byte rows, L2 resident).
 //
 // The reference recursions (/root/reference/src/EM.cpp:70-104) are strictly sequential in t.
 // They are compositions of associative maps, so each E-step is done in three phases per
@@ -24,14 +27,26 @@
 //                     entry state with the reference's own expressions and keeps J_t,
 //                     g_t = Xu_t - J_t Xp_{t+1}, h_t = Vu_t - J_t^2 Vp_{t+1} in registers.
 //  backward (:94-104) Xs_t = J_t Xs_{t+1} + g_t, Vs_t = J_t^2 Vs_{t+1} + h_t are affine maps:
-//                     (B1) compose per lane, (scan) reverse scan by DPP + three readlanes,
+//                     (B1) compose per lane, (scan) reverse scan by DPP + readlanes,
 //                     (B2) serial re-run from the exact entry value, then all M-step sums
 //                     (:151-193) in an independent pass.
 //  then ONE wave all-reduce of every sum (M-step and likelihood), the stop rule (:272) and the
 //  closed-form M-step (ldsr_device.h) redundantly in every lane.
 //
+// W > 1 (T > 2048): each wave scans its own 64 lanes exactly as above and the W waves of the
+// cell exchange three small records per iteration through LDS (workgroup = one cell, so plain
+// s_barrier): the wave's forward composite matrix, its reverse affine composite, and its partial
+// sums.  Every wave then forms the same totals in the same order, so theta, lik and the stop
+// decision are bit-identical in all waves of the cell.
+//
 // Chunks longer than 16 steps keep J/g/h for their second half only and re-run the first half's
-// forward recursion before its backward sweep (register budget: two waves per SIMD).
+// forward recursion before its backward sweep (register budget: two waves per SIMD).  Wide
+// inputs (padded p + q >= 12: nine or more LDS words per step) are compiled for one wave per
+// SIMD (512 registers) and carry e_t, B u_t from F1 to F2 in registers instead of re-forming them.
+//
+// FIT: the same machinery run for exactly one E-step at the given thetas, writing the full fit
+// X, Y, V, J (Kalman_smoother, src/EM.cpp:22-131) and optionally penalized_likelihood
+// (R/LDS_GA.R:28-44) -- the smoother of the winners' fits and of GA populations.
 //
 // Reassociation changes results at the 1e-12 level or below (measured against the oracle:
 // tools/parity_report.py); iteration counts are identical.
@@ -143,79 +158,95 @@ __device__ __forceinline__ PMat pdpp(const PMat &m) {
     return r;
 }
 
-// Lane <-> time mapping.  A cell uses nl = ceil(T/L) lanes; the first rp lanes own L
-// consecutive steps and lanes rp..nl-1 own L-1 (T = nl*(L-1) + rp), so steps 0..L-2 of every
-// active lane are real and only step L-1 is predicated: the unrolled loops are straight-line
-// code.  Lane l starts at t0 = l*(L-1) + min(l, rp).  Requires L*(L-1) <= T <= 64*L (see
-// scan_L_for in kernels_scan.hip).
+// Layout constants shared by the kernel, series_prep_kernel and the host.
+//
+// Lane <-> time mapping.  A cell uses nl = ceil(T/L) of its NL = 64 W virtual lanes; the first rp
+// own L consecutive steps and lanes rp..nl-1 own L-1 (T = nl*(L-1) + rp), so steps 0..L-2 of
+// every active lane are real and only step L-1 is predicated: the unrolled loops are
+// straight-line code.  Virtual lane l starts at t0 = l*(L-1) + min(l, rp).  Requires
+// L*(L-1) <= T <= NL*L (see scan_plan in kernels_scan.hip).
+//
+// Series image (doubles): y [L][NL] (0 where missing / unused), then u [L][PP][NL] (zero for
+// t = T-1), then v [L][QQ][NL]; element (step j, row k) of virtual lane l at [(j*K + k)*NL + l].
+__host__ __device__ constexpr long scan_image_doubles(int L, int W, int PP, int QQ) {
+    return (long)64 * W * L * (1 + PP + QQ);
+}
+// per-wave exchange records of a multi-wave cell (doubles): forward composite (8), reverse
+// composite (4), partial sums (XCH_SUMS), plus one slot for the queue pull
+#define XCH_SUMS 40
+__host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (8 + 4 + XCH_SUMS) + 2 : 0; }
 
+// padded p + q >= 12: one wave per SIMD with the 512-register budget (LDSR_WIDE_OCC1), and
+// e_t / B u_t kept in registers from F1 to F2 (LDSR_WIDE_EBR); both switchable for A/B builds
+#ifndef LDSR_WIDE_OCC1
+#define LDSR_WIDE_OCC1 1
+#endif
+#ifndef LDSR_WIDE_EBR
+#define LDSR_WIDE_EBR 1
+#endif
+__host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_OCC1 && PP + QQ >= 12; }
+__host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
-// GIMG = the series is read from the prepared time-major arrays in global memory (ys/us/vs are
-// then this lane's own row pointers) instead of the chunk-transposed LDS image.
-template <int PP, int QQ, int L, bool DENSE, bool GIMG>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
-                                             const double *us, const double *vs, int s, int cell,
-                                             int lane, int nl, int rp);
+                                             const double *us, const double *vs, double *xch,
+                                             int s, int cell, int lane, int wv, int nl, int rp);
 
 // QUEUE = waves pull cells from the per-series work queue (cells converge at different
 // iterations); !QUEUE = wave w of block b owns cell c0 + w (every cell runs exactly niter
 // iterations, i.e. tol == 0: nothing to balance, and the queue loop costs ~6 % in spill code).
-template <int PP, int QQ, int L, bool QUEUE, bool GIMG>
-__global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
+// GIMG = the series image is read from global memory instead of being copied to LDS.
+// W > 1: the workgroup is ONE group of W waves working on one cell at a time.
+template <int PP, int QQ, int L, int W, bool QUEUE, bool GIMG, bool FIT>
+__global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
-    // LDS image of the series, chunk-transposed: element (j, lane) of y at ys[j*64 + lane]
-    double *ys, *us, *vs;
-
+    constexpr int NL = 64 * W;
+    constexpr long IMG = scan_image_doubles(L, W, PP, QQ);
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
     const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];   // QUEUE: the series' cells; else the block's
     const int T = prm.T;
     const int lane = threadIdx.x & 63;
-    const int nl = (T + L - 1) / L;          // active lanes
+    const int wave = threadIdx.x >> 6;
+    const int nl = (T + L - 1) / L;          // active virtual lanes
     const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
+    const double *gimg = prm.img + (long)s * prm.img_stride;
+    const double *ys;
+    double *xch = nullptr;
     if constexpr (GIMG) {
-        // no LDS image: every lane reads its own rows of the prepared arrays (clamped for the
-        // idle lanes, which never use them)
-        const int t0 = min(lane, nl - 1) * (L - 1) + min(min(lane, nl - 1), rp);
-        ys = const_cast<double *>(prm.yz) + (long)s * T + t0;
-        us = const_cast<double *>(prm.up) + (long)s * prm.u_stride + (long)t0 * PP;
-        vs = const_cast<double *>(prm.vp) + (long)s * prm.v_stride + (long)t0 * QQ;
+        ys = gimg;
+        if constexpr (W > 1) xch = smem;
     } else {
-        ys = smem;                  // [L][64]       y, 0 where missing / unused
-        us = ys + 64 * L;           // [L][PP][64]   u_t, zero for t = T-1
-        vs = us + 64 * L * PP;      // [L][QQ][64]   v_t
-        const double *gy = prm.yp + (long)s * T;
-        const double *gu = prm.up + (long)s * prm.u_stride;
-        const double *gv = prm.vp + (long)s * prm.v_stride;
-        for (int i = threadIdx.x; i < 64 * L; i += blockDim.x) {
-            const int j = i >> 6, l = i & 63, t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            double yv = ok ? gy[t] : 0.0;
-            ys[i] = isfinite(yv) ? yv : 0.0;
-        }
-        for (int i = threadIdx.x; i < 64 * L * PP; i += blockDim.x) {
-            const int l = i & 63, jk = i >> 6, j = jk / PP, k = jk - j * PP;
-            const int t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            us[i] = ok ? gu[(long)t * PP + k] : 0.0;
-        }
-        for (int i = threadIdx.x; i < 64 * L * QQ; i += blockDim.x) {
-            const int l = i & 63, jk = i >> 6, j = jk / QQ, k = jk - j * QQ;
-            const int t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            vs[i] = ok ? gv[(long)t * QQ + k] : 0.0;
-        }
+        for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+        ys = smem;
+        if constexpr (W > 1) xch = smem + IMG;
+        __syncthreads();
     }
-    if constexpr (!GIMG) __syncthreads();
-    const bool dense = prm.sc[s].n_obs == T;
-    if constexpr (!QUEUE) {
-        const int wave = threadIdx.x >> 6;
+    const double *us = ys + NL * L;          // [L][PP][NL]
+    const double *vs = us + NL * L * PP;     // [L][QQ][NL]
+    const bool dense = prm.sc[s].n_obs == T && !FIT && W == 1;   // FIT / multi-wave: generic path only
+    if constexpr (W > 1) {
+        // one group: every wave of the workgroup works on the same cell
+        int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
+        if constexpr (!QUEUE) {
+            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT>(prm, ys, us, vs, xch, s, c0, lane, wave, nl, rp);
+        } else {
+            for (int pulls = 0; pulls <= nc; pulls++) {
+                if (threadIdx.x == 0) *qslot = atomicAdd(prm.queue + s, 1);
+                __syncthreads();
+                const int k = __builtin_amdgcn_readfirstlane(*(volatile int *)qslot);
+                __syncthreads();              // everyone has read the slot before the next pull
+                if (k >= nc) break;
+                em_scan_cell<PP, QQ, L, W, false, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, wave, nl, rp);
+            }
+        }
+    } else if constexpr (!QUEUE) {
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
         if (dense)
-            em_scan_cell<PP, QQ, L, true, GIMG>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, true, FIT>(prm, ys, us, vs, xch, s, c0 + wave, lane, 0, nl, rp);
         else
-            em_scan_cell<PP, QQ, L, false, GIMG>(prm, ys, us, vs, s, c0 + wave, lane, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, false, FIT>(prm, ys, us, vs, xch, s, c0 + wave, lane, 0, nl, rp);
     } else {
         // Work queue: every wave pulls cells of this series until the counter passes the
         // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
@@ -228,34 +259,38 @@ __global__ __launch_bounds__(512) void em_scan_kernel(EmParams prm) {
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
             if (dense)
-                em_scan_cell<PP, QQ, L, true, GIMG>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+                em_scan_cell<PP, QQ, L, 1, true, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, 0, nl, rp);
             else
-                em_scan_cell<PP, QQ, L, false, GIMG>(prm, ys, us, vs, s, c0 + k, lane, nl, rp);
+                em_scan_cell<PP, QQ, L, 1, false, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, 0, nl, rp);
         }
     }
 }
 
-template <int PP, int QQ, int L, bool DENSE, bool GIMG>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
-                                             const double *us, const double *vs, int s, int cell,
-                                             int lane, int nl, int rp) {
+                                             const double *us, const double *vs, double *xch,
+                                             int s, int cell, int lane, int wv, int nl, int rp) {
+    constexpr int NL = 64 * W;
+    constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
+    const int vl = wv * 64 + lane;            // virtual lane
     // element (step j, row k) of this lane's chunk of y / u / v
-    auto Yat = [&](int j) { return GIMG ? ys[j] : ys[j * 64 + lane]; };
-    auto Uat = [&](int j, int k) { return GIMG ? us[j * PP + k] : us[(j * PP + k) * 64 + lane]; };
-    auto Vat = [&](int j, int k) { return GIMG ? vs[j * QQ + k] : vs[(j * QQ + k) * 64 + lane]; };
+    auto Yat = [&](int j) { return ys[j * NL + vl]; };
+    auto Uat = [&](int j, int k) { return us[(j * PP + k) * NL + vl]; };
+    auto Vat = [&](int j, int k) { return vs[(j * QQ + k) * NL + vl]; };
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
     const int n_obs = sc->n_obs;
-    const bool act = lane < nl;      // this lane owns time steps
-    const bool tail = lane < rp;     // ... and its chunk has the L-th step
-    const int lastLane = nl - 1;     // owner of step T-1
+    const bool act = vl < nl;        // this lane owns time steps
+    const bool tail = vl < rp;       // ... and its chunk has the L-th step
+    const int lastW = (nl - 1) >> 6, lastLane = (nl - 1) & 63;   // owner of step T-1
+    const bool lastOwner = W == 1 || wv == lastW;
+    const int t0 = vl * (L - 1) + min(vl, rp);
 
     // observation mask of this lane's chunk
     unsigned obsmask = 0;
     if (!DENSE && act) {
         const double *gy = prm.yp + (long)s * T;
-        const int t0 = lane * (L - 1) + min(lane, rp);
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const double yv = (j < L - 1 || tail) ? gy[t0 + j] : NAN;
@@ -265,14 +300,28 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     Theta<PP, QQ> th;
     load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-    if (sc->status != 0) {
-        if (lane == 0) {
-            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+    if (sc->status != 0) {     // uniform over the cell's waves: no barrier is skipped unevenly
+        if (lane == 0 && wv == 0) {
+            if constexpr (!FIT) {
+                for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+                prm.n_iter[cell] = 0;
+                if (prm.liks && prm.liks_nanfill)
+                    for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            }
             prm.lik[cell] = NAN;
-            prm.n_iter[cell] = 0;
             prm.status[cell] = 2;
-            if (prm.liks && prm.liks_nanfill)
-                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            if (FIT && prm.pen) prm.pen[cell] = NAN;
+        }
+        if constexpr (FIT) {
+            if (act)
+                for (int j = 0; j < L; j++)
+                    if (j < L - 1 || tail) {
+                        const long o = (long)cell * T + t0 + j;
+                        if (prm.fitX) prm.fitX[o] = NAN;
+                        if (prm.fitY) prm.fitY[o] = NAN;
+                        if (prm.fitV) prm.fitV[o] = NAN;
+                        if (prm.fitJ) prm.fitJ[o] = NAN;
+                    }
         }
         return;
     }
@@ -287,6 +336,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     constexpr int HS = (L > 16) ? L / 2 : 0;   // L in {20, 24, 28, 32}
     constexpr int NS = L - HS;
     double Jv[NS], gv_[NS], hv[NS];
+    double ev[EBR ? L : 1], buv[EBR ? L : 1];
+    double Jfin = 0.0;      // FIT: J[T-1] of src/EM.cpp:98 (the backward recursion itself uses 0)
 
     for (;;) {
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
@@ -294,7 +345,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         const double rR = fast_rcp(R);
         const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
 
-        // e_t = y_t - D v_t (innovation minus C Xp) and bu_t = B u_t of step j of this lane, from LDS
+        // e_t = y_t - D v_t (innovation minus C Xp) and bu_t = B u_t of step j of this lane
         auto e_at = [&](int j) {
             double e = Yat(j);
 #pragma unroll
@@ -314,6 +365,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         auto f1 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
             const double e = e_at(j), bu = bu_at(j);
+            if constexpr (EBR) { ev[j] = e; buv[j] = bu; }
             const double a00 = o ? alpha : A2;
             const double g = o ? C2R : 0.0;
             const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
@@ -323,9 +375,10 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                 M = pstep(a00, Q, g, s20, bu, A, M);
             }
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
+            if constexpr (EBR) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
-            if (L <= 16) {
+            if (L <= 16 || EBR) {
 #pragma unroll
                 for (int j = 0; j < L - 1; j++) f1(j);
             } else {           // no register arrays here: keep long chunks rolled (code size, VGPRs)
@@ -346,25 +399,47 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
         // ... then row totals: lane 15 -> row 1, lane 47 -> row 3
         M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));
-        // M composes lanes 0..l (rows 0,1) or 32..l (rows 2,3).  State after this lane's chunk:
-        // rows 0,1 apply M to the initial state, rows 2,3 to the state of lane 31 (a matrix-vector
-        // product instead of a sixth matrix-matrix round).
-        double n_e = fma(M.m00, th.V1, M.m01);
-        double d_e = fma(M.m10, th.V1, M.m11);
-        double x_e = fma(M.m20, th.V1, fma(M.m22, th.mu1, M.m21));
+        // M composes lanes 0..l (rows 0,1) or 32..l (rows 2,3) of this wave.
+        // State entering the wave: the initial state, or (W > 1) the composites of the waves
+        // before this one applied to it.
+        double n_in = th.V1, d_in = 1.0, x_in = th.mu1;
+        if constexpr (W > 1) {
+            // this wave's composite = (lanes 32..63) o (lanes 0..31), formed in lane 63
+            PMat Cw = pmul(M, pdpp<DPP_ROW_BCAST31, 0xC>(M));
+            prenorm(Cw);
+            double *fx = xch + wv * 8;
+            if (lane == 63) {
+                fx[0] = Cw.m00; fx[1] = Cw.m01; fx[2] = Cw.m10; fx[3] = Cw.m11;
+                fx[4] = Cw.m20; fx[5] = Cw.m21; fx[6] = Cw.m22;
+            }
+            __syncthreads();
+            for (int k = 0; k < wv; k++) {
+                const double *c = xch + k * 8;
+                const double nn = fma(c[0], n_in, c[1] * d_in);
+                const double dd = fma(c[2], n_in, c[3] * d_in);
+                const double xx = fma(c[4], n_in, fma(c[5], d_in, c[6] * x_in));
+                n_in = nn; d_in = dd; x_in = xx;
+            }
+            n_in = uniform_d(n_in); d_in = uniform_d(d_in); x_in = uniform_d(x_in);
+        }
+        // State after this lane's chunk: rows 0,1 apply M to the wave's entry state, rows 2,3 to
+        // the state of lane 31 (a matrix-vector product instead of a sixth matrix-matrix round).
+        double n_e = fma(M.m00, n_in, M.m01 * d_in);
+        double d_e = fma(M.m10, n_in, M.m11 * d_in);
+        double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
         {
-            const double n_b = dppd<DPP_ROW_BCAST31, 0xC>(th.V1, n_e);
-            const double d_b = dppd<DPP_ROW_BCAST31, 0xC>(1.0, d_e);
-            const double x_b = dppd<DPP_ROW_BCAST31, 0xC>(th.mu1, x_e);
+            const double n_b = dppd<DPP_ROW_BCAST31, 0xC>(n_in, n_e);
+            const double d_b = dppd<DPP_ROW_BCAST31, 0xC>(d_in, d_e);
+            const double x_b = dppd<DPP_ROW_BCAST31, 0xC>(x_in, x_e);
             n_e = fma(M.m00, n_b, M.m01 * d_b);
             d_e = fma(M.m10, n_b, M.m11 * d_b);
             x_e = fma(M.m20, n_b, fma(M.m21, d_b, M.m22 * x_b));
         }
         // shift by one lane: the entry state of lane l is the exit state of lane l-1; lane 0
-        // gets the initial state (V1, 1, mu1)
-        n_e = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, n_e);
-        d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
-        x_e = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, x_e);
+        // gets the wave's entry state
+        n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
+        d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
+        x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
         double Xp, Vp;
         {
             const double rd = fast_rcp(d_e);
@@ -373,7 +448,10 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         }
 
         // ------------------------------------------------ F2: serial re-run from the exact entry
+        // log-determinant: running product of the observed Sigma_t, folded into (mantissa,
+        // exponent) every 8 steps so that it can neither overflow nor underflow (:122 sums logs)
         double likq = 0.0, sprod = 1.0, Xu = 0.0, Vu = 0.0;
+        int sexp = 0;
         int sneg = 0;   // OR of the sign words of every observed Sigma_t
         double sg = fma(C2, Vp, R);     // Sigma_t of the current step (src/EM.cpp:119)
         double r0 = fast_rcp(sg);
@@ -381,11 +459,15 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         double Pi = 1.0, G = 0.0, H = 0.0;                     // reverse composite (HS > 0 only)
         auto f2 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double e = e_at(j), bu = bu_at(j);
+            const double e = EBR ? ev[j] : e_at(j), bu = EBR ? buv[j] : bu_at(j);
             const double r = o ? r0 : 0.0;             // 1/Sigma_t; 0 = "no update" (:82-84)
             const double sl = o ? sg : 1.0;
             sprod *= sl;
             sneg |= __double2hiint(sl);
+            if ((j & 7) == 7) {
+                sexp += __builtin_amdgcn_frexp_exp(sprod);
+                sprod = __builtin_amdgcn_frexp_mant(sprod);
+            }
             const double w = Vp * r;
             const double K = C * w;                    // :86
             if (DENSE) Vu = R * w;                     // (1 - K C) Vp = R Vp / Sigma   :88
@@ -407,7 +489,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                 // Step T-1 starts the backward recursion: Xs_{T-1} = Xu_{T-1}, Vs_{T-1} = Vu_{T-1}
                 // (:94-95).  Expressed as J = 0, g = Xu, h = Vu with a zero terminal value,
                 // which also makes the (T-1, T) term of every pair sum vanish.
-                const bool fin = (lane == lastLane) && (j == (tail ? L - 1 : L - 2));
+                const bool fin = lastOwner && (lane == lastLane) && (j == (tail ? L - 1 : L - 2));
+                if (FIT && fin) Jfin = J;              // J[T-1] = Vu A / (A Vu A + Q)   :98
                 J = fin ? 0.0 : J;
                 g = fin ? Xu : g;
                 h = fin ? Vu : h;
@@ -427,12 +510,14 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             for (int j = 0; j < L - 1; j++) f2(j);
             if (tail) f2(L - 1);
         }
-        const double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);   // Xs^2 + Vs at T-1
+        // Xs^2 + Vs at T-1 (0 in the waves that do not own it)
+        double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);
+        if (W > 1 && !lastOwner) termLast = 0.0;
 
         // The two likelihood sums ride along with the M-step sums in ONE wave reduction at the end
         // of the iteration; the backward sweep of the final iteration is therefore redundant
         // (1 of n_iter sweeps) but every iteration saves 6 dependent cross-lane rounds.
-        const double lsp = log(sprod);
+        const double lsp = fma((double)sexp, 0.69314718055994530942, log(sprod));
 
         // ------------------------------------------------ B1: compose the reverse affine maps
         auto b1 = [&](int j) {
@@ -461,6 +546,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 #undef RSCAN_ROUND
         // ... then across rows: lanes 16, 32, 48 hold the composites T1, T2, T3 of rows 1..3;
         // every lane applies the composite of all rows after its own (uniform values)
+        double Xt = 0.0, Vt = 0.0;     // Xs, Vs just after this wave's last step (0 = terminal)
         {
             const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
             const double P2 = readlane_d(Pi, 32), G2 = readlane_d(G, 32), H2 = readlane_d(H, 32);
@@ -472,15 +558,33 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             const double Hs = row == 0 ? H123 : row == 1 ? H23 : row == 2 ? H3 : 0.0;
             G = fma(Pi, Gs, G);
             H = fma(Pi * Pi, Hs, H);
+            if constexpr (W > 1) {
+                // (G, H) assume a zero value after the wave's last lane; the true one comes from
+                // the waves after this one: publish (product of J, G, H) of the whole wave (lane 0)
+                const double P3 = readlane_d(Pi, 48);
+                const double P23 = P2 * P3, P123 = P1 * P23;
+                const double Ptot = Pi * (row == 0 ? P123 : row == 1 ? P23 : row == 2 ? P3 : 1.0);
+                double *bx = xch + W * 8 + wv * 4;
+                if (lane == 0) { bx[0] = Ptot; bx[1] = G; bx[2] = H; }
+                __syncthreads();
+                for (int k = W - 1; k > wv; k--) {
+                    const double *c = xch + W * 8 + k * 4;
+                    Xt = fma(c[0], Xt, c[1]);
+                    Vt = fma(c[0] * c[0], Vt, c[2]);
+                }
+                Xt = uniform_d(Xt); Vt = uniform_d(Vt);
+                G = fma(Ptot, Xt, G);
+                H = fma(Ptot * Ptot, Vt, H);
+            }
         }
-        // (G, H) = (Xs, Vs) at the first step of this lane's chunk (terminal value is zero);
-        // the entry for lane l is lane l+1's value, zero beyond the last active lane (inactive
-        // lanes hold identity maps, so their G = H = 0)
-        double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
-        double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
+        // (G, H) = (Xs, Vs) at the first step of this lane's chunk; the entry for lane l is lane
+        // l+1's value, and the value after the wave for lane 63 (inactive lanes hold identity
+        // maps, so they pass the terminal value through)
+        double Xn = dppd<DPP_WAVE_SHL1, 0xF>(Xt, G);
+        double Vn = dppd<DPP_WAVE_SHL1, 0xF>(Vt, H);
 
         // ------------------------------------------------ B2: serial reverse re-run + M-step sums
-        double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, term = 0.0;
+        double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, term = 0.0, aSsq = 0.0;
         double aSxv[QQ], aTx1u[PP], aTux[PP];
 #pragma unroll
         for (int k = 0; k < QQ; k++) aSxv[k] = 0.0;
@@ -506,20 +610,39 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             const double Xnx = top ? XnE : gv_[top ? i : i + 1];
             const double Vnx = top ? VnE : hv[top ? i : i + 1];
             aTx1x = fma(Xnx, Xs, fma(Vnx, J, aTx1x));   // :180  (zero at t = T-1)
+            double bu = 0.0;
 #pragma unroll
             for (int k = 0; k < PP; k++) {
                 const double ut = Uat(j, k);                      // zero at t = T-1
                 aTx1u[k] = fma(Xnx, ut, aTx1u[k]);                // :190
                 aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
+                if (FIT) bu = fma(th.B[k], ut, bu);
             }
             term = fma(Xs, Xs, Vs);
             aPall += term;                                        // :181,:183
             const double xo = o ? Xs : 0.0;
             aSyx = fma(Yat(j), xo, aSyx);                         // :151
             if (!DENSE) aSxx += o ? term : 0.0;                   // :152
+            double dv = 0.0;
 #pragma unroll
-            for (int k = 0; k < QQ; k++) aSxv[k] = fma(xo, Vat(j, k), aSxv[k]);  // :159
-            if (L > 16 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < QQ; k++) {
+                const double vt = Vat(j, k);
+                aSxv[k] = fma(xo, vt, aSxv[k]);                   // :159
+                if (FIT) dv = fma(th.D[k], vt, dv);
+            }
+            if constexpr (FIT) {
+                // the fit of src/EM.cpp:126-130 at time t0 + j, and the penalty term of
+                // R/LDS_GA.R:34-40 (steps t < T-1 only)
+                const bool fin = lastOwner && (lane == lastLane) && (j == (tail ? L - 1 : L - 2));
+                const long o_ = (long)cell * T + t0 + j;
+                if (prm.fitX) prm.fitX[o_] = Xs;
+                if (prm.fitV) prm.fitV[o_] = Vs;
+                if (prm.fitJ) prm.fitJ[o_] = fin ? Jfin : J;
+                if (prm.fitY) prm.fitY[o_] = fma(th.C, Xs, dv);   // :106-110
+                const double d = Xnx - fma(th.A, Xs, bu);
+                aSsq = fin ? aSsq : fma(d, d, aSsq);
+            }
+            if ((L > 16 && (j & 3) == 3) || EBR) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
             if (tail) b2a(NS - 1);
@@ -536,7 +659,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             double Xq = Xp0, Vq = Vp0, sgq = sg0, rq = r00;
             auto f2r = [&](int j) {
                 const bool o = DENSE || ((obsmask >> j) & 1u);
-                const double e = e_at(j), bu = bu_at(j);
+                const double e = EBR ? ev[j] : e_at(j), bu = EBR ? buv[j] : bu_at(j);
                 const double r = o ? rq : 0.0;
                 const double w = Vq * r;
                 const double K = C * w;
@@ -574,38 +697,80 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         }
         const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
         Sums<PP, QQ> S;
+        double ssq = 0.0;
         {
-            constexpr int NR = 5 + (DENSE ? 0 : 1) + QQ + 2 * PP;
+            constexpr int NB = 5 + (DENSE ? 0 : 1);          // fixed part
+            constexpr int NR = NB + QQ + 2 * PP + (FIT ? 1 : 0);
+            static_assert(NR + 5 <= XCH_SUMS, "exchange record too small");
             double red[NR];
             red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
             if (!DENSE) red[5] = aSxx;
-            constexpr int o0 = 5 + (DENSE ? 0 : 1);
 #pragma unroll
-            for (int k = 0; k < QQ; k++) red[o0 + k] = aSxv[k];
+            for (int k = 0; k < QQ; k++) red[NB + k] = aSxv[k];
 #pragma unroll
-            for (int k = 0; k < PP; k++) { red[o0 + QQ + k] = aTx1u[k]; red[o0 + QQ + PP + k] = aTux[k]; }
+            for (int k = 0; k < PP; k++) { red[NB + QQ + k] = aTx1u[k]; red[NB + QQ + PP + k] = aTux[k]; }
+            if (FIT) red[NR - 1] = aSsq;
             wave_sum_n<NR>(red);
+            double term0 = readlane_d(term, 0);        // Xs^2 + Vs at t = 0 (wave 0)
+            S.X0 = readlane_d(Xs, 0);                  // :218  (wave 0)
+            S.V0 = readlane_d(Vs, 0);                  // :219
+            bool neg = __any(sneg < 0);                // log of a negative Sigma in the reference
+            if constexpr (W > 1) {
+                // partial sums of the W waves -> totals, formed by every wave in the same order
+                double *sx = xch + W * 12 + wv * XCH_SUMS;
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NR; i++) sx[i] = red[i];
+                    sx[NR] = termLast; sx[NR + 1] = term0; sx[NR + 2] = S.X0; sx[NR + 3] = S.V0;
+                    sx[NR + 4] = neg ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                const double *s0 = xch + W * 12;
+#pragma unroll
+                for (int i = 0; i < NR; i++) {
+                    double a = s0[i];
+                    for (int k = 1; k < W; k++) a += s0[k * XCH_SUMS + i];
+                    red[i] = uniform_d(a);
+                }
+                double tl = 0.0, ng = 0.0;
+                for (int k = 0; k < W; k++) { tl += s0[k * XCH_SUMS + NR]; ng += s0[k * XCH_SUMS + NR + 4]; }
+                termLast = uniform_d(tl);
+                neg = __builtin_amdgcn_readfirstlane((int)(ng > 0.0)) != 0;
+                term0 = uniform_d(s0[NR + 1]);
+                S.X0 = uniform_d(s0[NR + 2]);
+                S.V0 = uniform_d(s0[NR + 3]);
+            }
             S.Syx = red[0]; S.Tx1x = red[1];
             S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
-            for (int k = 0; k < QQ; k++) S.Sxv[k] = red[o0 + k];
+            for (int k = 0; k < QQ; k++) S.Sxv[k] = red[NB + k];
 #pragma unroll
-            for (int k = 0; k < PP; k++) { S.Tx1u[k] = red[o0 + QQ + k]; S.Tux[k] = red[o0 + QQ + PP + k]; }
+            for (int k = 0; k < PP; k++) { S.Tx1u[k] = red[NB + QQ + k]; S.Tux[k] = red[NB + QQ + PP + k]; }
+            if (FIT) ssq = red[NR - 1];
             S.Txx = red[2] - termLast;                  // t = 0 .. T-2
-            S.Tx1x1 = red[2] - readlane_d(term, 0);     // t = 1 .. T-1
+            S.Tx1x1 = red[2] - term0;                   // t = 1 .. T-1
             // likelihood (:113-124)
             lik2 = lik1;
             lik1 = lik;
-            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;
-            if (__any(sneg < 0)) lik = NAN;   // log of a negative Sigma in the reference
+            lik = -0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4]);
+            if (!FIT || prm.stdlik) lik = lik / n_obs;
+            if (neg) lik = NAN;
+            if constexpr (FIT) {
+                if (prm.pen && lane == 0 && wv == 0) {
+                    const double full = (prm.stdlik ? lik * n_obs : lik);
+                    prm.pen[cell] = full - prm.lambda * ssq;
+                }
+            }
         }
-        if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + it] = lik;
+        if constexpr (FIT) {
+            it = 1;
+            break;
+        }
+        if (prm.liks && lane == 0 && wv == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
         bool stop = it >= prm.niter;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
-        S.X0 = readlane_d(Xs, 0);                       // :218
-        S.V0 = readlane_d(Vs, 0);                       // :219
         mstep_update<PP, QQ, true>(th, S, sc, T);
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
@@ -616,28 +781,28 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
     }
 
-    if (lane == 0) {
-        store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
-        if (prm.liks && prm.liks_nanfill)
-            for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+    if (lane == 0 && wv == 0) {
+        if constexpr (!FIT) {
+            store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+            if (prm.liks && prm.liks_nanfill)
+                for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            prm.n_iter[cell] = it;
+        }
         prm.lik[cell] = lik;
-        prm.n_iter[cell] = it;
         prm.status[cell] = isfinite(lik) ? 0 : 1;
     }
 }
 
-// waves per block so that a CU holds ~8 waves given the LDS image of one series
-static inline int scan_wpb(int L, int PP, int QQ) {
-    const size_t lds = (size_t)64 * L * (1 + PP + QQ) * sizeof(double);
-    const int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int want = 8;
-    int wpb = (want + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
-    if (wpb < 2) wpb = 2;
-    if (L <= 16 && wpb < 4 && lds > 20 * 1024) wpb = 4;
-    const int cap = 8;
-    return wpb > cap ? cap : wpb;
-}
+// Launch plan of a (T, PP, QQ) shape: chunk length, waves per cell, cells per workgroup, and
+// whether the series image is read from global memory (kernels_scan.hip).
+struct ScanPlan {
+    int L = 0, W = 0;
+    int cpb = 0;        // cells (= wave groups) per workgroup
+    bool gimg = false;
+    bool ok = false;
+};
+ScanPlan scan_plan(int T, int PP, int QQ);
 
-template <int L>
-hipError_t launch_em_scan_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,
-                            hipStream_t stream);
+template <int L, int W>
+hipError_t launch_em_scan_LW(const EmParams &prm, int PPv, int QQv, int n_blocks, int cpb,
+                             bool queue, bool gimg, bool fit, hipStream_t stream);

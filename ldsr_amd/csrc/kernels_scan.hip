@@ -1,68 +1,92 @@
-// kernels_scan.hip -- chooses the chunk length L (time steps per lane) of the wave-per-cell
-// scan kernel and dispatches to the per-L translation units (em_scan_L*.hip).
-#include "em_scan_impl.h"
+// kernels_scan.hip -- launch plan of the parallel-in-time scan kernel (chunk length L, waves
+// per cell W, LDS or global series image) and dispatch to the per-(L, W) translation units
+// (em_scan_L*.hip).
 #include <cstdio>
+#include <cstdlib>
 
+#include "em_scan_impl.h"
 #include "ldsr_kernels.h"
 
-// smallest compiled chunk length with T <= 64*L; every choice also satisfies L*(L-1) <= T
-static int scan_L_for(int T) {
+static const size_t kLdsBytes = 160 * 1024;
+
+// waves per block so that a CU holds ~8 waves given the LDS image of one series
+static int scan_wpb(int L, int PP, int QQ) {
+    if (scan_wide(PP, QQ)) return 4;      // one wave per SIMD (512-register kernels)
+    const size_t lds = (size_t)scan_image_doubles(L, 1, PP, QQ) * sizeof(double);
+    const int blocks_per_cu = (int)(kLdsBytes / lds);
+    const int want = 8;
+    int wpb = (want + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    if (wpb < 2) wpb = 2;
+    if (L <= 16 && wpb < 4 && lds > 20 * 1024) wpb = 4;
+    const int cap = 8;
+    return wpb > cap ? cap : wpb;
+}
+
+// W = 1: smallest compiled chunk length with T <= 64 L (every choice also has L (L-1) <= T).
+// T > 2048: W = 2 (T <= 4096) or 4 (T <= 8192) waves per cell with half-stored chunks.
+ScanPlan scan_plan(int T, int PP, int QQ) {
+    ScanPlan p;
+    if (PP > 8 || QQ > 8 || T < 2) return p;   // instantiated for padded widths up to 8
     static const int Ls[] = {2, 3, 4, 6, 8, 10, 12, 13, 14, 15, 16, 20, 24, 28, 32};
-    for (int L : Ls)
-        if (T <= 64 * L) return (T >= L * (L - 1)) ? L : 0;
-    return 0;
+    static const int LsW[] = {20, 24, 28, 32};
+    if (T <= 2048) {
+        p.W = 1;
+        for (int L : Ls)
+            if (T <= 64 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
+    } else if (T <= 8192) {
+        p.W = T <= 4096 ? 2 : 4;
+        for (int L : LsW)
+            if (T <= 64 * p.W * L) { p.L = L; break; }
+    }
+    if (!p.L) return p;
+    const size_t lds = (size_t)(scan_image_doubles(p.L, p.W, PP, QQ) + scan_xch_doubles(p.W)) * sizeof(double);
+    // the image is read from global memory when it does not fit a CU's LDS (L >= 20 only: the
+    // short-chunk images always fit); four-wave cells are compiled in that form only
+    size_t lim = kLdsBytes;
+    if (const char *e = getenv("LDSR_SCAN_LDS_IMAGE_MAX_BYTES")) lim = (size_t)strtoull(e, nullptr, 10);
+    p.gimg = p.L >= 20 && (p.W == 4 || lds > kLdsBytes || (p.W == 2 && lds > lim));
+    if (!p.gimg && lds > kLdsBytes) return p;
+    p.cpb = p.W > 1 ? 1 : (p.gimg ? 4 : scan_wpb(p.L, PP, QQ));   // GIMG: two workgroups per CU by VGPRs
+    p.ok = true;
+    return p;
 }
 
-static bool lds_image_fits(int L, int PP, int QQ) {
-    return (size_t)64 * L * (1 + PP + QQ) * sizeof(double) <= 160 * 1024;
+bool em_scan_supported(int T, int PP, int QQ) { return scan_plan(T, PP, QQ).ok; }
+bool em_scan_global_image(int T, int PP, int QQ) { return scan_plan(T, PP, QQ).gimg; }
+int em_scan_cells_per_block(int T, int PP, int QQ) { return scan_plan(T, PP, QQ).cpb; }
+// shapes compiled with the work-queue schedule only: global-image and multi-wave kernels
+bool em_scan_queue_only(int T, int PP, int QQ) {
+    const ScanPlan p = scan_plan(T, PP, QQ);
+    return p.gimg || p.W > 1;
+}
+void em_scan_layout(int T, int PP, int QQ, int *L, int *NL, long *img_doubles) {
+    const ScanPlan p = scan_plan(T, PP, QQ);
+    *L = p.L;
+    *NL = 64 * p.W;
+    *img_doubles = p.ok ? scan_image_doubles(p.L, p.W, PP, QQ) : 0;
 }
 
-bool em_scan_supported(int T, int PP, int QQ) {
-    const int L = scan_L_for(T);
-    if (!L || PP > 8 || QQ > 8) return false;   // instantiated for padded widths up to 8
-    return lds_image_fits(L, PP, QQ) || L >= 20; // L >= 20 also exists in a global-image variant
+void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len) {
+    const ScanPlan p = scan_plan(T, PP, QQ);
+    queue = !fit && (queue || p.gimg || p.W > 1);
+    snprintf(buf, len, "em_scan_kernel<%d, %d, %d, %d, %s, %s, %s>", PP, QQ, p.L, p.W,
+             queue ? "true" : "false", p.gimg ? "true" : "false", fit ? "true" : "false");
 }
 
-// Long series with wide inputs: the chunk-transposed LDS image would exceed 160 KiB; the kernel
-// variant GIMG reads the prepared time-major arrays straight from global memory (L2 resident).
-bool em_scan_global_image(int T, int PP, int QQ) {
-    const int L = scan_L_for(T);
-    return L >= 20 && PP <= 8 && QQ <= 8 && !lds_image_fits(L, PP, QQ);
-}
-
-int em_scan_cells_per_block(int T, int PP, int QQ) {
-    if (em_scan_global_image(T, PP, QQ)) return 4;     // no LDS image: two workgroups per CU by VGPRs
-    return scan_wpb(scan_L_for(T), PP, QQ);
-}
-
-bool em_scan_queue_only(int T, int PP, int QQ) { return em_scan_global_image(T, PP, QQ); }
-
-void em_scan_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len) {
-    const bool gimg = em_scan_global_image(T, PP, QQ);
-    snprintf(buf, len, "em_scan_kernel<%d, %d, %d, %s, %s>", PP, QQ, scan_L_for(T),
-             (queue || gimg) ? "true" : "false", gimg ? "true" : "false");
-}
-
-hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue, bool fit,
                           hipStream_t stream) {
-    const int wpb = em_scan_cells_per_block(prm.T, PP, QQ);
-    if (em_scan_global_image(prm.T, PP, QQ)) queue = true;   // GIMG exists with the queue schedule only
-    switch (scan_L_for(prm.T)) {
-        case 2: return launch_em_scan_L<2>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 3: return launch_em_scan_L<3>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 4: return launch_em_scan_L<4>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 6: return launch_em_scan_L<6>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 8: return launch_em_scan_L<8>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 10: return launch_em_scan_L<10>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 12: return launch_em_scan_L<12>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 13: return launch_em_scan_L<13>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 14: return launch_em_scan_L<14>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 15: return launch_em_scan_L<15>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 16: return launch_em_scan_L<16>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 20: return launch_em_scan_L<20>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 24: return launch_em_scan_L<24>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 28: return launch_em_scan_L<28>(prm, PP, QQ, n_blocks, wpb, queue, stream);
-        case 32: return launch_em_scan_L<32>(prm, PP, QQ, n_blocks, wpb, queue, stream);
+    const ScanPlan p = scan_plan(prm.T, PP, QQ);
+    if (!p.ok) return hipErrorInvalidValue;
+    queue = !fit && (queue || p.gimg || p.W > 1);
+#define CASE_LW(Lv, Wv) \
+    case Lv * 8 + Wv: return launch_em_scan_LW<Lv, Wv>(prm, PP, QQ, n_blocks, p.cpb, queue, p.gimg, fit, stream);
+    switch (p.L * 8 + p.W) {
+        CASE_LW(2, 1) CASE_LW(3, 1) CASE_LW(4, 1) CASE_LW(6, 1) CASE_LW(8, 1) CASE_LW(10, 1)
+        CASE_LW(12, 1) CASE_LW(13, 1) CASE_LW(14, 1) CASE_LW(15, 1) CASE_LW(16, 1)
+        CASE_LW(20, 1) CASE_LW(24, 1) CASE_LW(28, 1) CASE_LW(32, 1)
+        CASE_LW(20, 2) CASE_LW(24, 2) CASE_LW(28, 2) CASE_LW(32, 2)
+        CASE_LW(20, 4) CASE_LW(24, 4) CASE_LW(28, 4) CASE_LW(32, 4)
         default: return hipErrorInvalidValue;
     }
+#undef CASE_LW
 }

@@ -101,6 +101,33 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
         }
     }
+    if (prm.img) {
+        // chunk-transposed image of the scan kernel (layout: em_scan_impl.h): element (step j,
+        // row k) of virtual lane l at [(j*K + k)*NL + l]; 0 where missing / beyond the chunk
+        double *im = prm.img + (long)s * prm.img_stride;
+        const int L = prm.L, NL = prm.NL;
+        const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+        for (int i = tid; i < NL * L; i += 256) {
+            const int j = i / NL, l = i - j * NL, t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            const double yv = ok ? y[t] : 0.0;
+            im[i] = isfinite(yv) ? yv : 0.0;
+        }
+        double *imu = im + (long)NL * L;
+        for (int i = tid; i < NL * L * PP; i += 256) {
+            const int l = i % NL, jk = i / NL, j = jk / PP, k = jk - j * PP;
+            const int t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            imu[i] = (ok && u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
+        }
+        double *imv = imu + (long)NL * L * PP;
+        for (int i = tid; i < NL * L * QQ; i += 256) {
+            const int l = i % NL, jk = i / NL, j = jk / QQ, k = jk - j * QQ;
+            const int t = l * (L - 1) + min(l, rp) + j;
+            const bool ok = l < nl && (j < L - 1 || l < rp);
+            imv[i] = (ok && v && k < q) ? v[(long)t * q + k] : 0.0;
+        }
+    }
     // identity / zero padding of the statistics
     for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
         const double id = ((i / LDSR_MAXPQ) == (i % LDSR_MAXPQ)) ? 1.0 : 0.0;

@@ -282,9 +282,9 @@ static int cells_per_block(int algo, int T, int PP, int QQ) {
 }
 
 struct WsLayout {
-    size_t sc, yp, yz, up, vp, blk, soc, queue, scratch, total;
-    long scratch_stride;
-    int max_blocks;
+    size_t sc, yp, yz, up, vp, img, blk, soc, queue, scratch, total;
+    long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
+    int max_blocks, img_L, img_NL;
 };
 
 static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, int n_cells,
@@ -297,6 +297,10 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     const size_t nuv = shared_uv ? 1 : (size_t)n_series;
     L.up = o; o = align256(o + sizeof(double) * nuv * T * PP);
     L.vp = o; o = align256(o + sizeof(double) * nuv * T * QQ);
+    // chunk-transposed images for the scan kernel (also built for serial-kernel EM launches
+    // whose shape the scan kernel supports: the winners' fit then runs on the scan kernel)
+    em_scan_layout(T, PP, QQ, &L.img_L, &L.img_NL, &L.img_stride);
+    L.img = o; o = align256(o + sizeof(double) * (size_t)L.img_stride * n_series);
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
@@ -353,7 +357,7 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
-        if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), buf, len);
+        if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
         if (buf && len) em_serial_kernel_name(T, PP, QQ, buf, len);
     } else {
@@ -375,6 +379,10 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.vp = (double *)(ws + L.vp);
     pp.sc = (SeriesConst *)(ws + L.sc);
     pp.queue = (int *)(ws + L.queue);
+    pp.img = L.img_stride ? (double *)(ws + L.img) : nullptr;
+    pp.img_stride = L.img_stride;
+    pp.L = L.img_L;
+    pp.NL = L.img_NL;
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -399,7 +407,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN) return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
-        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8");
+        return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
     const int cpb = cells_per_block(algo, T, PP, QQ);
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo, cpb);
     if (workspace_bytes < L.total)
@@ -450,6 +458,11 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.vp = (const double *)(ws + L.vp);
     prm.u_stride = shared_uv ? 0 : (long)T * PP;
     prm.v_stride = shared_uv ? 0 : (long)T * QQ;
+    prm.img = (const double *)(ws + L.img);
+    prm.img_stride = L.img_stride;
+    prm.fitX = prm.fitY = prm.fitV = prm.fitJ = prm.pen = nullptr;
+    prm.lambda = 0.0;
+    prm.stdlik = 1;
     prm.sc = (const SeriesConst *)(ws + L.sc);
     prm.blk_series = d_tab;
     prm.blk_cell0 = d_tab + n_blocks;
@@ -463,7 +476,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     int slot;
     HIPCHK(prof_begin(device, stream, &slot));
     if (algo == LDSR_ALGO_SCAN)
-        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, stream));
+        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
     else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
     HIPCHK(prof_end(stream, slot));
@@ -479,6 +492,89 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
     return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
                                 shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
                                 d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes);
+}
+
+// One Kalman_smoother pass (src/EM.cpp:22-131) for n cells on prepared series: the FIT form of
+// the scan kernel (one wave group per cell) whenever the shape is supported, else the serial
+// one-thread-per-cell kernel.  blk_*: host block table rows (series, first cell, cells) of the
+// scan launch; it travels through the pinned staging ring.  d_tab: device room for 3*n_blocks
+// ints.  mode: 0 smoother, 1 propagate (serial kernel only).
+static int launch_smoother(int device, hipStream_t stream, int T, int p, int q, int PP, int QQ,
+                           bool has_u, bool has_v, int shared_uv, char *ws, const WsLayout &L,
+                           int n, const std::vector<int> &series_of_cell, const double *d_theta,
+                           int stdlik, int mode, double lambda, double *d_X, double *d_Y,
+                           double *d_V, double *d_J, double *d_lik, double *d_pen, int *d_status,
+                           int *d_soc, bool scalar_only) {
+    if (mode == 0 && L.img_stride && em_scan_supported(T, PP, QQ)) {
+        const int cpb = em_scan_cells_per_block(T, PP, QQ);
+        std::vector<int> bs, bc, bn;
+        for (int c = 0; c < n;) {               // blocks never straddle a series
+            int e = c + 1;
+            while (e < n && e - c < cpb && series_of_cell[(size_t)e] == series_of_cell[(size_t)c]) e++;
+            bs.push_back(series_of_cell[(size_t)c]);
+            bc.push_back(c);
+            bn.push_back(e - c);
+            c = e;
+        }
+        const int n_blocks = (int)bs.size();
+        if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow (fit)");
+        std::vector<int> tab;
+        tab.insert(tab.end(), bs.begin(), bs.end());
+        tab.insert(tab.end(), bc.begin(), bc.end());
+        tab.insert(tab.end(), bn.begin(), bn.end());
+        int *d_tab = (int *)(ws + L.blk);
+        int rc = stage_h2d_async(device, stream, d_tab, tab.data(), sizeof(int) * tab.size());
+        if (rc) return rc;
+        EmParams prm;
+        memset(&prm, 0, sizeof(prm));
+        prm.T = T; prm.p = p; prm.q = q; prm.has_u = has_u; prm.has_v = has_v;
+        prm.niter = 1; prm.n_cells = n; prm.tol = 0.0;
+        prm.yp = (const double *)(ws + L.yp);
+        prm.yz = (const double *)(ws + L.yz);
+        prm.up = (const double *)(ws + L.up);
+        prm.vp = (const double *)(ws + L.vp);
+        prm.u_stride = shared_uv ? 0 : (long)T * PP;
+        prm.v_stride = shared_uv ? 0 : (long)T * QQ;
+        prm.img = (const double *)(ws + L.img);
+        prm.img_stride = L.img_stride;
+        prm.sc = (const SeriesConst *)(ws + L.sc);
+        prm.blk_series = d_tab;
+        prm.blk_cell0 = d_tab + n_blocks;
+        prm.blk_ncell = d_tab + 2 * n_blocks;
+        prm.queue = (int *)(ws + L.queue);
+        prm.theta0 = d_theta;
+        prm.lik = d_lik;
+        prm.status = d_status;
+        prm.fitX = scalar_only ? nullptr : d_X; prm.fitY = scalar_only ? nullptr : d_Y;
+        prm.fitV = scalar_only ? nullptr : d_V; prm.fitJ = scalar_only ? nullptr : d_J;
+        prm.pen = d_pen;
+        prm.lambda = lambda;
+        prm.stdlik = stdlik;
+        HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, false, true, stream));
+        return LDSR_OK;
+    }
+    int rc = stage_h2d_async(device, stream, d_soc, series_of_cell.data(), sizeof(int) * (size_t)n);
+    if (rc) return rc;
+    SmoothParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.T = T; sp.p = p; sp.q = q; sp.has_u = has_u; sp.has_v = has_v;
+    sp.n_cells = n; sp.stdlik = stdlik; sp.mode = mode;
+    sp.lambda = lambda;
+    sp.yp = (const double *)(ws + L.yp);
+    sp.up = (const double *)(ws + L.up);
+    sp.vp = (const double *)(ws + L.vp);
+    sp.u_stride = shared_uv ? 0 : (long)T * PP;
+    sp.v_stride = shared_uv ? 0 : (long)T * QQ;
+    sp.sc = (const SeriesConst *)(ws + L.sc);
+    sp.series_of_cell = d_soc;
+    sp.theta = d_theta;
+    sp.X = d_X; sp.Y = d_Y; sp.V = d_V; sp.J = d_J;
+    sp.lik = d_lik;
+    sp.status = d_status;
+    sp.pen = d_pen;
+    sp.scalar_only = scalar_only;
+    HIPCHK(launch_smooth(sp, PP, QQ, stream));
+    return LDSR_OK;
 }
 
 // ---- one contiguous slice of the cell grid on one device ---------------------------------------
@@ -660,23 +756,16 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
         if (rc) return rc;
     }
     // the winners' fit: one smoother pass at theta_w on the prepared series
-    SmoothParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.T = T; sp.p = S.p; sp.q = S.q; sp.has_u = S.u != nullptr; sp.has_v = S.v != nullptr;
-    sp.n_cells = n_w; sp.stdlik = 1; sp.mode = 0;
-    sp.yp = (const double *)(ws + S.L.yp);
-    sp.up = (const double *)(ws + S.L.up);
-    sp.vp = (const double *)(ws + S.L.vp);
-    sp.u_stride = S.shared_uv ? 0 : (long)T * S.PP;
-    sp.v_stride = S.shared_uv ? 0 : (long)T * S.QQ;
-    sp.sc = (const SeriesConst *)(ws + S.L.sc);
-    sp.series_of_cell = (const int *)(dw + W.ser);
-    sp.theta = (const double *)(dw + W.theta);
-    sp.X = (double *)(dw + W.X); sp.Y = (double *)(dw + W.Y);
-    sp.V = (double *)(dw + W.V); sp.J = (double *)(dw + W.J);
-    sp.lik = (double *)(dw + W.lik);
-    sp.status = (int *)(dw + W.st);
-    if (X || Y || V || J) HIPCHK(launch_smooth(sp, S.PP, S.QQ, A->stream));
+    if (X || Y || V || J) {
+        std::vector<int> soc(w_series, w_series + n_w);
+        int rc = launch_smoother(S.device, A->stream, T, S.p, S.q, S.PP, S.QQ, S.u != nullptr,
+                                 S.v != nullptr, S.shared_uv, ws, S.L, n_w, soc,
+                                 (const double *)(dw + W.theta), 1, 0, 0.0, (double *)(dw + W.X),
+                                 (double *)(dw + W.Y), (double *)(dw + W.V), (double *)(dw + W.J),
+                                 (double *)(dw + W.lik), nullptr, (int *)(dw + W.st),
+                                 (int *)(dw + W.ser), false);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(pw + W.out_begin, dw + W.out_begin, W.out_bytes, hipMemcpyDeviceToHost,
                           A->stream));
     HIPCHK(hipStreamSynchronize(A->stream));
@@ -931,7 +1020,9 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     rc = arena_acquire(device, &lease.a);
     if (rc) return rc;
     Arena *A = lease.a;
-    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, LDSR_ALGO_SCAN, 64);
+    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, LDSR_ALGO_SCAN, 1);
+    // the serial smoother uses X / V as its filtered-state strip; the scan FIT kernel needs none
+    const bool need_strip = !(mode == 0 || mode == 3) || !em_scan_supported(T, PP, QQ);
     Carver c;
     const size_t o_y = c.take(sizeof(double) * (size_t)n_series * T);
     const size_t o_u = c.take(u ? sizeof(double) * nuv * T * p : 0);
@@ -944,8 +1035,8 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     const size_t o_st = c.take(sizeof(int) * (size_t)n_cells);
     const size_t o_tho = c.take(sizeof(double) * (size_t)n_cells * P);
     const size_t small_out = c.o - o_lik;
-    const size_t o_X = c.take(sizeof(double) * nT);     // X / V double as the filtered-state strip
-    const size_t o_V = c.take(sizeof(double) * nT);
+    const size_t o_X = c.take((scalar_only && !need_strip) ? 0 : sizeof(double) * nT);
+    const size_t o_V = c.take((scalar_only && !need_strip) ? 0 : sizeof(double) * nT);
     const size_t o_Y = c.take(scalar_only ? 0 : sizeof(double) * nT);
     const size_t o_J = c.take(scalar_only ? 0 : sizeof(double) * nT);
     const size_t o_ws = c.take(L.total);
@@ -966,28 +1057,26 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
                         v ? (const double *)(dev + o_v) : nullptr, shared_uv, ws, L);
     if (rc) return rc;
 
-    SmoothParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.T = T; sp.p = p; sp.q = q; sp.has_u = u != nullptr; sp.has_v = v != nullptr;
-    sp.n_cells = n_cells; sp.stdlik = stdlik; sp.mode = (mode == 3) ? 0 : mode;
-    sp.lambda = lambda;
-    sp.yp = (const double *)(ws + L.yp);
-    sp.up = (const double *)(ws + L.up);
-    sp.vp = (const double *)(ws + L.vp);
-    sp.u_stride = shared_uv ? 0 : (long)T * PP;
-    sp.v_stride = shared_uv ? 0 : (long)T * QQ;
-    sp.sc = (const SeriesConst *)(ws + L.sc);
-    sp.series_of_cell = (const int *)(dev + o_soc);
-    sp.X = (double *)(dev + o_X); sp.Y = (double *)(dev + o_Y);
-    sp.V = (double *)(dev + o_V); sp.J = (double *)(dev + o_J);
-    sp.lik = (double *)(dev + o_lik);
-    sp.status = (int *)(dev + o_st);
+    std::vector<int> soc_v(soc, soc + n_cells);
     char *pout = pin + in_bytes;
     if (mode == 2) {
         // the fit arrives from the caller: X, V, J rows straight into the device arrays
         HIPCHK(hipMemcpyAsync(dev + o_X, X, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
         HIPCHK(hipMemcpyAsync(dev + o_V, V, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
         HIPCHK(hipMemcpyAsync(dev + o_J, J, sizeof(double) * nT, hipMemcpyHostToDevice, A->stream));
+        SmoothParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.T = T; sp.p = p; sp.q = q; sp.has_u = u != nullptr; sp.has_v = v != nullptr;
+        sp.n_cells = n_cells;
+        sp.yp = (const double *)(ws + L.yp);
+        sp.up = (const double *)(ws + L.up);
+        sp.vp = (const double *)(ws + L.vp);
+        sp.u_stride = shared_uv ? 0 : (long)T * PP;
+        sp.v_stride = shared_uv ? 0 : (long)T * QQ;
+        sp.sc = (const SeriesConst *)(ws + L.sc);
+        sp.series_of_cell = (const int *)(dev + o_soc);
+        sp.X = (double *)(dev + o_X); sp.V = (double *)(dev + o_V); sp.J = (double *)(dev + o_J);
+        sp.status = (int *)(dev + o_st);
         sp.theta_out = (double *)(dev + o_tho);
         HIPCHK(launch_mstep(sp, PP, QQ, A->stream));
         HIPCHK(hipMemcpyAsync(pout, dev + o_lik, small_out, hipMemcpyDeviceToHost, A->stream));
@@ -996,10 +1085,13 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
         if (status) memcpy(status, pout + (o_st - o_lik), sizeof(int) * (size_t)n_cells);
         return LDSR_OK;
     }
-    sp.theta = (const double *)(dev + o_th);
-    sp.pen = scalar_only ? (double *)(dev + o_pen) : nullptr;
-    sp.scalar_only = scalar_only;
-    HIPCHK(launch_smooth(sp, PP, QQ, A->stream));
+    rc = launch_smoother(device, A->stream, T, p, q, PP, QQ, u != nullptr, v != nullptr, shared_uv,
+                         ws, L, n_cells, soc_v, (const double *)(dev + o_th), stdlik,
+                         mode == 1 ? 1 : 0, lambda, (double *)(dev + o_X), (double *)(dev + o_Y),
+                         (double *)(dev + o_V), (double *)(dev + o_J), (double *)(dev + o_lik),
+                         scalar_only ? (double *)(dev + o_pen) : nullptr, (int *)(dev + o_st),
+                         (int *)(dev + o_soc), scalar_only);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(pout, dev + o_lik, small_out, hipMemcpyDeviceToHost, A->stream));
     HIPCHK(hipStreamSynchronize(A->stream));
     if (scalar_only) {

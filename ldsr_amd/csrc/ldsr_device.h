@@ -166,6 +166,8 @@ struct EmParams {
     const double *up;        // [n_series or 1][T][PP]  zero padded, row T-1 zeroed
     const double *vp;        // [n_series or 1][T][QQ]
     long u_stride, v_stride; // doubles per series (0 when shared)
+    const double *img;       // scan kernel: [n_series] chunk-transposed series images (see em_scan_impl.h)
+    long img_stride;         // doubles per series image
     const SeriesConst *sc;   // [n_series]
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
@@ -174,6 +176,11 @@ struct EmParams {
     int *n_iter, *status;
     double *scratch;         // serial kernel: [T][2][scratch_stride]
     long scratch_stride;
+    // FIT variant of the scan kernel (one E-step at theta0, the full fit written out)
+    double *fitX, *fitY, *fitV, *fitJ;   // [n_cells][T], any may be null
+    double *pen;             // lik(stdlik = FALSE) - lambda * ssq  (R/LDS_GA.R:28-44), may be null
+    double lambda;
+    int stdlik;              // divide lik by n_obs (src/EM.cpp:124)
 };
 
 #define LDSR_LOG_2PI 1.8378770664093454835606594728112

@@ -9,6 +9,9 @@ struct PrepParams {
     const double *y, *u, *v;  // raw inputs as handed over the ABI (u / v may be null)
     double *yp, *up, *vp;     // prepared copies in the workspace
     double *yz;               // y with 0 where missing
+    double *img;              // scan kernel: chunk-transposed series images [n_series][img_stride], or null
+    long img_stride;          // doubles per image
+    int L, NL;                // chunk length and virtual lanes (64 W) of the image layout
     SeriesConst *sc;
     int *queue;               // [n_series] work-queue heads, reset to 0 here
 };
@@ -44,14 +47,15 @@ static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream);
 hipError_t launch_em_serial(const EmParams &prm, int PP, int QQ, int n_blocks, hipStream_t stream);
-hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
+hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue, bool fit,
                           hipStream_t stream);
+void em_scan_layout(int T, int PP, int QQ, int *L, int *NL, long *img_doubles);
 bool em_scan_global_image(int T, int PP, int QQ);   // series image too large for LDS: read from L2
 bool em_scan_queue_only(int T, int PP, int QQ);     // shapes compiled with the work-queue schedule only
 bool em_scan_supported(int T, int PP, int QQ);
 int em_scan_cells_per_block(int T, int PP, int QQ);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
-void em_scan_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len);
+void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);
 hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);

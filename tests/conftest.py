@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:        # PyTorch's bundled HIP runtime must initialise before libldsr_hip.so's (tests that hand
+    import torch  # noqa: F401  torch device buffers to the C ABI); the reverse order leaves torch without a GPU
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

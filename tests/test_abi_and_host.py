@@ -66,7 +66,9 @@ def test_argument_validation_without_gpu():
     # serial needs the [t][cell] strip, scan does not
     assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 1) >= 2 * 1000 * 4096 * 8
     assert L.ldsr_em_workspace_bytes(1, 1000, 1, 2, 4096, 2) < 1 << 20
-    assert L.ldsr_em_workspace_bytes(1, 5000, 1, 2, 64, 2) == 0     # scan kernel: T <= 2048
+    assert L.ldsr_em_workspace_bytes(1, 5000, 1, 2, 64, 2) > 0      # four waves per cell
+    assert L.ldsr_em_workspace_bytes(1, 9000, 1, 2, 64, 2) == 0     # scan kernel: T <= 8192
+    assert L.ldsr_em_workspace_bytes(1, 9000, 1, 2, 64, 0) > 0      # AUTO: serial kernel
 
 
 def test_no_cpu_fallback():

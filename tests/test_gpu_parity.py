@@ -201,7 +201,7 @@ def test_synthetic_converged_runs(eng, O, algo, T, p, q, mask, n):
     from ldsr_amd import synth
     y, u, v = synth.make_series(T, p, q, series_id=T + p + q, mask=mask)
     th0 = synth.make_init_packed(p, q, n, seed=T)
-    if algo == 2 and T > 2048:
+    if algo == 2 and T > 8192:
         with pytest.raises(Exception):
             eng.em_batch(y, u, v, th0, niter=1000, tol=1e-5, algo=algo)
         algo = 0                     # LDSR_ALGO_AUTO falls back to the serial kernel

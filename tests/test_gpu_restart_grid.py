@@ -93,7 +93,7 @@ def test_restart_grid_series_without_a_selectable_winner(eng):
     all-NA gives integer(0)): winner -1 and NaN rows, the other folds are unaffected."""
     Y, u, v, off, th0, p, q = _cv_like(F=3, R=4)
     th0 = th0.copy()
-    th0[off[1]:off[2], 3 + p + q] = -5.0         # R < 0 in every restart of fold 1: log(Sigma) = NaN
+    th0[off[1]:off[2], 0] = np.nan               # NaN A in every restart of fold 1: NaN likelihoods throughout
     r = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=3, tol=0.0)
     assert np.all(np.isnan(r["all"]["lik"][off[1]:off[2]]))
     assert r["winner"][1] == -1 and r["winner"][0] >= 0 and r["winner"][2] >= 0
