@@ -179,13 +179,17 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 // padded p + q >= 12: one wave per SIMD with the 512-register budget (LDSR_WIDE_OCC1), and
 // e_t / B u_t kept in registers from F1 to F2 (LDSR_WIDE_EBR); both switchable for A/B builds
 #ifndef LDSR_WIDE_OCC1
-#define LDSR_WIDE_OCC1 1
+#define LDSR_WIDE_OCC1 0
 #endif
 #ifndef LDSR_WIDE_EBR
-#define LDSR_WIDE_EBR 1
+#define LDSR_WIDE_EBR 0
+#endif
+#ifndef LDSR_WIDE_SB      // scheduling barrier after every step of the wide kernels' sweeps
+#define LDSR_WIDE_SB 0
 #endif
 __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_OCC1 && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
+__host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
 
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
 template <int PP, int QQ, int L, int W, bool DENSE, bool FIT>
@@ -272,6 +276,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                                              int s, int cell, int lane, int wv, int nl, int rp) {
     constexpr int NL = 64 * W;
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
+    constexpr bool SB = scan_sb(PP, QQ);
     const int vl = wv * 64 + lane;            // virtual lane
     // element (step j, row k) of this lane's chunk of y / u / v
     auto Yat = [&](int j) { return ys[j * NL + vl]; };
@@ -375,7 +380,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                 M = pstep(a00, Q, g, s20, bu, A, M);
             }
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
-            if constexpr (EBR) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
             if (L <= 16 || EBR) {
@@ -503,7 +508,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             }
             Xp = Xp1;
             Vp = Vp1;
-            if (L > 16) __builtin_amdgcn_sched_barrier(0);
+            if (L > 16 || SB) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
 #pragma unroll
@@ -642,7 +647,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                 const double d = Xnx - fma(th.A, Xs, bu);
                 aSsq = fin ? aSsq : fma(d, d, aSsq);
             }
-            if ((L > 16 && (j & 3) == 3) || EBR) __builtin_amdgcn_sched_barrier(0);
+            if ((L > 16 && (j & 3) == 3) || SB) __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
             if (tail) b2a(NS - 1);

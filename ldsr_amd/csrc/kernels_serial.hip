@@ -552,19 +552,73 @@ __global__ __launch_bounds__(64) void mstep_kernel(SmoothParams prm) {
 __global__ __launch_bounds__(128) void gather_winners_kernel(GatherParams prm) {
     const int i = blockIdx.x;
     const long c = prm.cell[i];
+    const bool has = c >= 0;
     for (int k = threadIdx.x; k < prm.P; k += 128) {
-        prm.theta_w[(long)i * prm.P + k] = prm.theta[c * prm.P + k];
-        prm.theta0_w[(long)i * prm.P + k] = prm.theta0[c * prm.P + k];
+        prm.theta_w[(long)i * prm.P + k] = has ? prm.theta[c * prm.P + k] : NAN;
+        prm.theta0_w[(long)i * prm.P + k] = has ? prm.theta0[c * prm.P + k] : NAN;
     }
     if (prm.liks) {
-        const int n = prm.n_iter[c];
+        const int n = has ? prm.n_iter[c] : 0;
         for (int k = threadIdx.x; k < prm.niter; k += 128)
             prm.liks_w[(long)i * prm.niter + k] = k < n ? prm.liks[c * prm.niter + k] : NAN;
+    }
+    if (threadIdx.x == 0) {
+        if (prm.lik_w) prm.lik_w[i] = has ? prm.lik[c] : NAN;
+        if (prm.n_iter_w) prm.n_iter_w[i] = has ? prm.n_iter[c] : 0;
+        if (prm.blk) {
+            prm.blk[i] = i;                          // series of the block
+            prm.blk[prm.n_w + i] = i;                // its first cell: row i of the winner arrays
+            prm.blk[2 * prm.n_w + i] = has ? 1 : 0;  // no winner: the block has nothing to do
+        }
     }
 }
 
 hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream) {
     hipLaunchKernelGGL(gather_winners_kernel, dim3(prm.n_w), dim3(128), 0, stream, prm);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// select_winners_kernel: the reference's selection rule per series -- highest lik among the
+// restarts with C > 0 if there is one, else among all; NaN ignored; first index on ties.
+// Same result as the host routine ldsr_select_restart (max is order independent, ties go to
+// the lowest index).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_winners_kernel(SelectParams prm) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int a = prm.off[s], b = prm.off[s + 1];
+    __shared__ double sl[256];
+    __shared__ int si[256];
+    int any = 0;
+    for (int c = a + tid; c < b; c += 256) any |= prm.theta[(long)c * prm.P + prm.c_index] > 0 ? 1 : 0;
+    any = __syncthreads_or(any);
+    double best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = a + tid; c < b; c += 256) {
+        const double lk = prm.lik[c];
+        if (isnan(lk)) continue;
+        if (any && !(prm.theta[(long)c * prm.P + prm.c_index] > 0)) continue;
+        if (lk > best || (lk == best && c < bi)) { best = lk; bi = c; }
+    }
+    sl[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) {
+            const double ol = sl[tid + d];
+            const int oi = si[tid + d];
+            if (oi != 0x7fffffff && (si[tid] == 0x7fffffff || ol > sl[tid] || (ol == sl[tid] && oi < si[tid]))) {
+                sl[tid] = ol;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) prm.winner[s] = si[0] == 0x7fffffff ? -1 : si[0];
+}
+
+hipError_t launch_select_winners(const SelectParams &prm, hipStream_t stream) {
+    hipLaunchKernelGGL(select_winners_kernel, dim3(prm.n_series), dim3(256), 0, stream, prm);
     return hipGetLastError();
 }
 

@@ -504,27 +504,32 @@ static int launch_smoother(int device, hipStream_t stream, int T, int p, int q, 
                            int n, const std::vector<int> &series_of_cell, const double *d_theta,
                            int stdlik, int mode, double lambda, double *d_X, double *d_Y,
                            double *d_V, double *d_J, double *d_lik, double *d_pen, int *d_status,
-                           int *d_soc, bool scalar_only) {
+                           int *d_soc, bool scalar_only, const int *d_tab_prebuilt = nullptr) {
     if (mode == 0 && L.img_stride && em_scan_supported(T, PP, QQ)) {
         const int cpb = em_scan_cells_per_block(T, PP, QQ);
-        std::vector<int> bs, bc, bn;
-        for (int c = 0; c < n;) {               // blocks never straddle a series
-            int e = c + 1;
-            while (e < n && e - c < cpb && series_of_cell[(size_t)e] == series_of_cell[(size_t)c]) e++;
-            bs.push_back(series_of_cell[(size_t)c]);
-            bc.push_back(c);
-            bn.push_back(e - c);
-            c = e;
+        const int *d_tab = d_tab_prebuilt;      // [3][n]: one block per cell, filled on the device
+        int n_blocks = n;
+        if (!d_tab) {
+            std::vector<int> bs, bc, bn;
+            for (int c = 0; c < n;) {               // blocks never straddle a series
+                int e = c + 1;
+                while (e < n && e - c < cpb && series_of_cell[(size_t)e] == series_of_cell[(size_t)c]) e++;
+                bs.push_back(series_of_cell[(size_t)c]);
+                bc.push_back(c);
+                bn.push_back(e - c);
+                c = e;
+            }
+            n_blocks = (int)bs.size();
+            if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow (fit)");
+            std::vector<int> tab;
+            tab.insert(tab.end(), bs.begin(), bs.end());
+            tab.insert(tab.end(), bc.begin(), bc.end());
+            tab.insert(tab.end(), bn.begin(), bn.end());
+            int *d_ws_tab = (int *)(ws + L.blk);
+            int rc = stage_h2d_async(device, stream, d_ws_tab, tab.data(), sizeof(int) * tab.size());
+            if (rc) return rc;
+            d_tab = d_ws_tab;
         }
-        const int n_blocks = (int)bs.size();
-        if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow (fit)");
-        std::vector<int> tab;
-        tab.insert(tab.end(), bs.begin(), bs.end());
-        tab.insert(tab.end(), bc.begin(), bc.end());
-        tab.insert(tab.end(), bn.begin(), bn.end());
-        int *d_tab = (int *)(ws + L.blk);
-        int rc = stage_h2d_async(device, stream, d_tab, tab.data(), sizeof(int) * tab.size());
-        if (rc) return rc;
         EmParams prm;
         memset(&prm, 0, sizeof(prm));
         prm.T = T; prm.p = p; prm.q = q; prm.has_u = has_u; prm.has_v = has_v;
@@ -592,13 +597,21 @@ struct Slice {
     double *theta = nullptr, *lik = nullptr, *liks = nullptr;
     int *n_iter = nullptr, *status = nullptr;
     int max_winners = 0;        // > 0: reserve phase-2 buffers and keep the traces on the device
+    // Fused restart path (the whole grid on this one slice): selection, winner gather and the
+    // winners' fit are enqueued right behind the EM kernel and everything comes back with ONE
+    // synchronisation; the per-cell arrays cross PCIe only if the caller asked for them.
+    bool fuse = false, want_all = true;
+    int *h_winner = nullptr, *h_nit_w = nullptr;
+    double *h_theta_w = nullptr, *h_lik_w = nullptr, *h_liks_w = nullptr;
+    double *h_X = nullptr, *h_Y = nullptr, *h_V = nullptr, *h_J = nullptr;
+    bool fused_done = false;
     // state
     ArenaLease lease;
     int n_cells = 0, PP = 0, QQ = 0, P = 0;
     bool trace_on_device = false;
     WsLayout L;
     size_t wsb = 0;
-    size_t d_in = 0, d_y = 0, d_u = 0, d_v = 0, d_th0 = 0, in_bytes = 0;      // device offsets
+    size_t d_in = 0, d_y = 0, d_u = 0, d_v = 0, d_th0 = 0, d_off = 0, in_bytes = 0;      // device offsets
     size_t d_out = 0, d_theta = 0, d_lik = 0, d_nit = 0, d_st = 0, out_bytes = 0;
     size_t d_liks = 0, d_ws = 0;
     size_t d_w = 0, w_bytes = 0;          // phase-2 device block
@@ -613,17 +626,18 @@ static size_t liks_trace_cap_bytes() {
 
 // phase-2 block layout for n winners (offsets relative to its start)
 struct WinLayout {
-    size_t cell, ser, theta, liks, X, Y, V, J, lik, st, theta0, total;
-    size_t out_begin, out_bytes;    // [theta | liks | X | Y | V | J | lik] is copied back
+    size_t cell, ser, theta, liks, X, Y, V, J, lik, st, theta0, blk, lik_w, nit_w, total;
+    size_t out_begin, out_bytes;    // [cell | theta | liks | X | Y | V | J | lik | lik_w | nit_w] is copied back
 };
 static WinLayout win_layout(int n, int P, int T, int niter) {
     WinLayout W;
     Carver c;
-    W.cell = c.take(sizeof(int) * n);
     W.ser = c.take(sizeof(int) * n);
     W.theta0 = c.take(sizeof(double) * n * P);
     W.st = c.take(sizeof(int) * n);
+    W.blk = c.take(sizeof(int) * 3 * n);
     W.out_begin = c.o;
+    W.cell = c.take(sizeof(int) * n);        // winners' cell indices (uploaded, or selected on the device)
     W.theta = c.take(sizeof(double) * n * P);
     W.liks = c.take(sizeof(double) * (size_t)n * niter);
     W.X = c.take(sizeof(double) * (size_t)n * T);
@@ -631,6 +645,8 @@ static WinLayout win_layout(int n, int P, int T, int niter) {
     W.V = c.take(sizeof(double) * (size_t)n * T);
     W.J = c.take(sizeof(double) * (size_t)n * T);
     W.lik = c.take(sizeof(double) * n);
+    W.lik_w = c.take(sizeof(double) * n);
+    W.nit_w = c.take(sizeof(int) * n);
     W.out_bytes = c.o - W.out_begin;
     W.total = c.o;
     return W;
@@ -654,6 +670,7 @@ static int slice_run(Slice &S) {
     S.d_u = c.take(S.u ? sizeof(double) * nuv * T * S.p : 0);
     S.d_v = c.take(S.v ? sizeof(double) * nuv * T * S.q : 0);
     S.d_th0 = c.take(sizeof(double) * (size_t)n * P);
+    S.d_off = c.take(sizeof(int) * ((size_t)S.n_series + 1));
     S.in_bytes = c.o - S.d_in;
     S.d_out = c.o;
     S.d_theta = c.take(sizeof(double) * (size_t)n * P);
@@ -689,6 +706,7 @@ static int slice_run(Slice &S) {
     if (S.u) memcpy(pin + (S.d_u - S.d_in), S.u, sizeof(double) * nuv * T * S.p);
     if (S.v) memcpy(pin + (S.d_v - S.d_in), S.v, sizeof(double) * nuv * T * S.q);
     memcpy(pin + (S.d_th0 - S.d_in), S.theta0, sizeof(double) * (size_t)n * P);
+    memcpy(pin + (S.d_off - S.d_in), S.off.data(), sizeof(int) * ((size_t)S.n_series + 1));
     HIPCHK(hipMemcpyAsync(A->dev + S.d_in, pin, S.in_bytes, hipMemcpyHostToDevice, A->stream));
 
     rc = em_batch_device_impl(
@@ -700,6 +718,74 @@ static int slice_run(Slice &S) {
         S.liks != nullptr, A->dev + S.d_ws, S.wsb);
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
+    if (S.fuse && S.trace_on_device) {
+        // selection, winner extraction and the winners' fit behind the EM kernel, one sync
+        const int ns = S.n_series;
+        char *dw = A->dev + S.d_w, *pw = A->pin + S.p_w;
+        SelectParams sel;
+        sel.n_series = ns; sel.P = P; sel.c_index = 1 + S.p;
+        sel.off = (const int *)(A->dev + S.d_off);
+        sel.theta = (const double *)(A->dev + S.d_theta);
+        sel.lik = (const double *)(A->dev + S.d_lik);
+        sel.winner = (int *)(dw + W.cell);
+        HIPCHK(launch_select_winners(sel, A->stream));
+        GatherParams gp;
+        gp.n_w = ns; gp.P = P; gp.niter = S.niter;
+        gp.cell = (const int *)(dw + W.cell);
+        gp.theta = sel.theta;
+        gp.theta0 = (const double *)(A->dev + S.d_th0);
+        gp.n_iter = (const int *)(A->dev + S.d_nit);
+        gp.liks = (const double *)(A->dev + S.d_liks);
+        gp.theta_w = (double *)(dw + W.theta);
+        gp.theta0_w = (double *)(dw + W.theta0);
+        gp.liks_w = (double *)(dw + W.liks);
+        gp.lik = sel.lik;
+        gp.lik_w = (double *)(dw + W.lik_w);
+        gp.n_iter_w = (int *)(dw + W.nit_w);
+        gp.blk = (int *)(dw + W.blk);
+        HIPCHK(launch_gather_winners(gp, A->stream));
+        const bool want_fit = S.h_X || S.h_Y || S.h_V || S.h_J;
+        if (want_fit) {
+            std::vector<int> soc((size_t)ns);
+            for (int i = 0; i < ns; i++) soc[(size_t)i] = i;
+            char *ws = A->dev + S.d_ws;
+            rc = launch_smoother(S.device, A->stream, T, S.p, S.q, S.PP, S.QQ, S.u != nullptr,
+                                 S.v != nullptr, S.shared_uv, ws, S.L, ns, soc,
+                                 (const double *)(dw + W.theta), 1, 0, 0.0, (double *)(dw + W.X),
+                                 (double *)(dw + W.Y), (double *)(dw + W.V), (double *)(dw + W.J),
+                                 (double *)(dw + W.lik), nullptr, (int *)(dw + W.st),
+                                 (int *)(dw + W.ser), false, (const int *)(dw + W.blk));
+            if (rc) return rc;
+        }
+        if (S.want_all)
+            HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
+        HIPCHK(hipMemcpyAsync(pw + W.out_begin, dw + W.out_begin, W.out_bytes, hipMemcpyDeviceToHost,
+                              A->stream));
+        HIPCHK(hipStreamSynchronize(A->stream));
+        if (S.want_all) {
+            memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
+            memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
+            memcpy(S.n_iter, pout + (S.d_nit - S.d_out), sizeof(int) * (size_t)n);
+            memcpy(S.status, pout + (S.d_st - S.d_out), sizeof(int) * (size_t)n);
+        }
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        memcpy(S.h_winner, pw + W.cell, sizeof(int) * ns);
+        memcpy(S.h_theta_w, pw + W.theta, sizeof(double) * (size_t)ns * P);
+        memcpy(S.h_lik_w, pw + W.lik_w, sizeof(double) * ns);
+        memcpy(S.h_nit_w, pw + W.nit_w, sizeof(int) * ns);
+        if (S.h_liks_w) memcpy(S.h_liks_w, pw + W.liks, sizeof(double) * (size_t)ns * S.niter);
+        double *rows[4] = {S.h_X, S.h_Y, S.h_V, S.h_J};
+        const size_t roff[4] = {W.X, W.Y, W.V, W.J};
+        for (int k = 0; k < 4; k++) {
+            if (!rows[k]) continue;
+            memcpy(rows[k], pw + roff[k], sizeof(double) * (size_t)ns * T);
+            for (int i = 0; i < ns; i++)      // series without a winner: the fit kernel skipped them
+                if (S.h_winner[i] < 0)
+                    for (int t = 0; t < T; t++) rows[k][(size_t)i * T + t] = nan;
+        }
+        S.fused_done = true;
+        return LDSR_OK;
+    }
     HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
     HIPCHK(hipStreamSynchronize(A->stream));
     memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
@@ -723,8 +809,8 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
     char *dw = A->dev + S.d_w, *pw = A->pin + S.p_w;
     memcpy(pw + W.cell, w_cell, sizeof(int) * n_w);
     memcpy(pw + W.ser, w_series, sizeof(int) * n_w);
-    HIPCHK(hipMemcpyAsync(dw + W.cell, pw + W.cell, W.ser + sizeof(int) * n_w - W.cell,
-                          hipMemcpyHostToDevice, A->stream));
+    HIPCHK(hipMemcpyAsync(dw + W.cell, pw + W.cell, sizeof(int) * n_w, hipMemcpyHostToDevice, A->stream));
+    HIPCHK(hipMemcpyAsync(dw + W.ser, pw + W.ser, sizeof(int) * n_w, hipMemcpyHostToDevice, A->stream));
     GatherParams gp;
     gp.n_w = n_w; gp.P = P; gp.niter = niter;
     gp.cell = (const int *)(dw + W.cell);
@@ -735,6 +821,7 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
     gp.theta_w = (double *)(dw + W.theta);
     gp.theta0_w = (double *)(dw + W.theta0);
     gp.liks_w = (double *)(dw + W.liks);
+    gp.lik = nullptr; gp.lik_w = nullptr; gp.n_iter_w = nullptr; gp.blk = nullptr;
     HIPCHK(launch_gather_winners(gp, A->stream));
     char *ws = A->dev + S.d_ws;
     if (!S.trace_on_device && liks_w) {
@@ -893,23 +980,41 @@ extern "C" int ldsr_em_restart_grid(int n_devices, const int *devices, int n_ser
     const int n_cells = cell_offsets[n_series];
     const int P = 6 + p + q;
     const double nan = std::numeric_limits<double>::quiet_NaN();
-    // per-cell results the caller did not ask for live in temporaries (selection needs them)
+    if (n_devices > n_cells) n_devices = n_cells > 0 ? n_cells : 1;
+    // One slice: selection and the winners' fit are fused behind the EM kernel on the device and
+    // the per-cell arrays cross PCIe only if asked for.  Several slices: per-cell results come
+    // back first (temporaries if the caller did not ask), the host selects, then phase 2 runs on
+    // the slice that owns each winner.
+    const bool want_all = theta_all || lik_all || n_iter_all || status_all;
+    const bool fused = n_devices == 1 && n_cells > 0 &&
+                       sizeof(double) * (size_t)n_cells * niter <= liks_trace_cap_bytes();
     std::vector<double> t_theta, t_lik;
     std::vector<int> t_nit, t_st;
-    if (!theta_all) { t_theta.resize((size_t)n_cells * P + 1); theta_all = t_theta.data(); }
-    if (!lik_all) { t_lik.resize((size_t)n_cells + 1); lik_all = t_lik.data(); }
-    if (!n_iter_all) { t_nit.resize((size_t)n_cells + 1); n_iter_all = t_nit.data(); }
-    if (!status_all) { t_st.resize((size_t)n_cells + 1); status_all = t_st.data(); }
-
-    if (n_devices > n_cells) n_devices = n_cells > 0 ? n_cells : 1;
+    if (!fused || want_all) {
+        if (!theta_all) { t_theta.resize((size_t)n_cells * P + 1); theta_all = t_theta.data(); }
+        if (!lik_all) { t_lik.resize((size_t)n_cells + 1); lik_all = t_lik.data(); }
+        if (!n_iter_all) { t_nit.resize((size_t)n_cells + 1); n_iter_all = t_nit.data(); }
+        if (!status_all) { t_st.resize((size_t)n_cells + 1); status_all = t_st.data(); }
+    }
     std::vector<Slice> sl;
     std::vector<int> lo_of, s0_of;
     make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
                 niter, tol, algo, theta_all, lik_all, n_iter_all, status_all, nullptr, lo_of, s0_of);
     for (Slice &S : sl) S.max_winners = S.n_series;
+    if (fused) {
+        Slice &S = sl[0];
+        S.fuse = true;
+        S.want_all = want_all;
+        S.h_winner = winner; S.h_theta_w = theta_w; S.h_lik_w = lik_w; S.h_nit_w = n_iter_w;
+        S.h_liks_w = liks_w; S.h_X = X; S.h_Y = Y; S.h_V = V; S.h_J = J;
+    }
     if (n_cells > 0) {
         rc = run_slices(sl);
         if (rc) return rc;
+        if (fused) {
+            if (!sl[0].fused_done) return fail(LDSR_EINVAL, "internal: fused restart path did not run");
+            return LDSR_OK;     // winner[] is already global (one slice: lo = 0)
+        }
     }
     // selection (R/LDS_reconstruction.R:50-58), per series over its restarts
     for (int s = 0; s < n_series; s++) {

@@ -31,16 +31,30 @@ struct SmoothParams {
     int scalar_only;      // only lik / pen leave the kernel: Y and J are not written
 };
 
-// Winner extraction of the restart-grid entry: row i of the *_w arrays = cell[i] of the batch.
+// Restart selection on the device (R/LDS_reconstruction.R:50-58), one workgroup per series.
+struct SelectParams {
+    int n_series, P, c_index;     // c_index: position of C in a packed theta (1 + p)
+    const int *off;               // [n_series + 1] cell offsets
+    const double *theta, *lik;    // [n_cells][P], [n_cells]
+    int *winner;                  // [n_series] cell index or -1
+};
+
+// Winner extraction of the restart-grid entry: row i of the *_w arrays = cell[i] of the batch
+// (cell[i] < 0: no winner -- NaN rows).  Optionally emits the FIT launch's block table
+// (series i, cell i, one cell or none) and the winners' lik / n_iter.
 struct GatherParams {
     int n_w, P, niter;
-    const int *cell;          // [n_w] cell index of each winner
+    const int *cell;          // [n_w] cell index of each winner, or -1
     const double *theta;      // [n_cells][P] fitted
     const double *theta0;     // [n_cells][P] initial
     const int *n_iter;        // [n_cells]
     const double *liks;       // [n_cells][niter] traces (entries beyond n_iter undefined), or null
     double *theta_w, *theta0_w;   // [n_w][P]
     double *liks_w;           // [n_w][niter], NaN padded (untouched when liks is null)
+    const double *lik;        // [n_cells] (with lik_w)
+    double *lik_w;            // [n_w] or null
+    int *n_iter_w;            // [n_w] or null
+    int *blk;                 // [3][n_w] block table (series, first cell, cells) or null
 };
 
 static inline int ldsr_pad_dim(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16; }
@@ -58,5 +72,6 @@ int em_scan_cells_per_block(int T, int PP, int QQ);
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);
 hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream);
+hipError_t launch_select_winners(const SelectParams &prm, hipStream_t stream);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);
 hipError_t launch_mstep(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);
