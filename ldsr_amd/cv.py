@@ -77,6 +77,33 @@ def calculate_metrics(sim, obs, z, norm_fun=np.nanmean):
             "KGE": KGE(sim[z], obs[z])}
 
 
+def tbrm(x, C=9.0):
+    """Tukey's biweight robust mean, the `use.robust.mean = TRUE` averaging of cvLDS
+    (R/LDS_reconstruction.R:397-398 -> dplR::tbrm; dplR is a third-party dependency that is not
+    under /root/reference, DESCRIPTION:21 `Imports: dplR`, version unpinned).  Published
+    algorithm (Mosteller & Tukey 1977, one step): weights (1 - u^2)^2 for |u| < 1 with
+    u = (x - median) / (C * MAD + 1e-6), MAD = median(|x - median|).  PARITY UNPINNED: the
+    reference holds no number computed with it (its stored NPcv$metrics are plain means,
+    tests/test_npcv_fixture.py)."""
+    x = np.asarray(x, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    m = np.median(x)
+    div = C * np.median(np.abs(x - m)) + 1e-6
+    u = (x - m) / div
+    w = np.where(np.abs(u) < 1.0, (1.0 - u * u) ** 2, 0.0)
+    return float(np.sum(w * x) / np.sum(w))
+
+
+def cv_metrics(Ycv, target, Z, robust_mean=True):
+    """Per-fold metrics and their mean as cvLDS returns them (R/LDS_reconstruction.R:395-398):
+    Ycv [n_folds, n_inst] in the metric space, target [n_inst], Z 0-based folds."""
+    dist = [calculate_metrics(Ycv[f], target, np.asarray(Z[f])) for f in range(len(Z))]
+    keys = list(dist[0])
+    cols = {k: np.array([d[k] for d in dist]) for k in keys}
+    mean = {k: (tbrm(cols[k]) if robust_mean else float(np.mean(cols[k]))) for k in keys}
+    return cols, mean
+
+
 def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed=1, r_seed=None,
             mu=0.0, device=0, devices=None, engine=None):
     """All folds x restarts in one launch.

@@ -1,18 +1,32 @@
 /*
  * ldsrhip_call.c -- R .Call shim over the C ABI of include/ldsr_hip.h (side-car DLL "ldsrhip").
  *
- * Pure marshalling: SEXP -> plain pointers -> libldsr_hip.so -> SEXP.  It replaces the
- * per-restart path  foreach(theta0 = init) %dopar% LDS_EM(...)  of the reference
- * (R/LDS_reconstruction.R:46 -> R/RcppExports.R:41-43 -> src/RcppExports.cpp:40-53) with ONE
- * call for all restarts.  Argument conventions are the reference's (src/RcppExports.cpp:44-49):
- * y 1xT REALSXP with NA = missing; u, v  pxT / qxT column-major REALSXP, or the 1x1 sentinel
- * `matrix(0)` for an absent input (detected by ncol == 1, as src/EM.cpp:50,71 do); init = list
- * of theta lists looked up BY NAME (src/EM.cpp:25-32); niter integer or double; tol double.
+ * Pure marshalling: SEXP -> plain pointers -> libldsr_hip.so -> SEXP.  Entry points and what
+ * they replace in the reference (paths under /root/reference):
+ *
+ *   ldsrhip_LDS_EM_batch(y, u, v, init, niter, tol)
+ *       the per-restart path  foreach(theta0 = init) %dopar% LDS_EM(...)  + the selection of
+ *       LDS_EM_restart (R/LDS_reconstruction.R:46-58): ONE call for all restarts
+ *   ldsrhip_LDS_EM_grid(Y, u, v, inits, niter, tol)
+ *       the fold loop of cvLDS (R/LDS_reconstruction.R:373-375 -> one_lds_cv :270-285): Y is a
+ *       T x F matrix, one column per fold (y with that fold's points set to NA, :274); inits is
+ *       a list of F init lists (fresh make_init per fold, :275); ONE call for folds x restarts,
+ *       returns a list of F winning models
+ *   ldsrhip_LDS_EM / ldsrhip_Kalman_smoother / ldsrhip_Mstep / ldsrhip_propagate
+ *       the four numeric entries of the registration table src/RcppExports.cpp:132-143
+ *       (_ldsr_LDS_EM :40, _ldsr_Kalman_smoother :11, _ldsr_Mstep :26, _ldsr_propagate :56),
+ *       same arguments and return shapes, for a full replacement of ldsr.so's EM path
+ *
+ * Argument conventions are the reference's (src/RcppExports.cpp:44-49): y 1xT REALSXP with NA =
+ * missing; u, v  pxT / qxT column-major REALSXP, or the 1x1 sentinel `matrix(0)` for an absent
+ * input (detected by ncol == 1, as src/EM.cpp:50,71 do); init = list of theta lists looked up BY
+ * NAME (src/EM.cpp:25-32); niter integer or double; tol double; stdlik logical.
  *
  * Build where R is installed (not possible in the build container: no R headers):
  *   R CMD SHLIB -o ldsrhip.so ldsrhip_call.c -L<repo>/ldsr_amd -lldsr_hip -I<repo>/include
  * Never longjmps across a HIP call: all device work happens inside ldsr_* calls that return
- * status codes; Rf_error is raised only after they have returned and freed device memory.
+ * status codes; Rf_error is raised only after they have returned (device buffers are cached by
+ * the library and released by ldsr_shutdown() at unload).
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -21,11 +35,14 @@
 
 #include "ldsr_hip.h"
 
+static const char *const THETA_NAMES[8] = {"A", "B", "C", "D", "Q", "R", "mu1", "V1"};
+
 static SEXP list_get(SEXP lst, const char *name) {
     SEXP nm = Rf_getAttrib(lst, R_NamesSymbol);
-    for (R_xlen_t i = 0; i < Rf_xlength(lst); i++)
-        if (strcmp(CHAR(STRING_ELT(nm, i)), name) == 0) return VECTOR_ELT(lst, i);
-    Rf_error("theta: element '%s' not found", name);
+    if (nm != R_NilValue)
+        for (R_xlen_t i = 0; i < Rf_xlength(lst); i++)
+            if (strcmp(CHAR(STRING_ELT(nm, i)), name) == 0) return VECTOR_ELT(lst, i);
+    Rf_error("element '%s' not found", name);
     return R_NilValue;
 }
 
@@ -35,109 +52,278 @@ static SEXP mat(int nr, int nc, const double *src) { /* caller PROTECTs */
     return m;
 }
 
-/* packed theta [A, B(p), C, D(q), Q, R, mu1, V1] -> named list of matrices (src/EM.cpp:221-228) */
+static SEXP named_list(int n, const char *const *names, SEXP *out_names) { /* both PROTECTed by the caller's count */
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, n)), nm = PROTECT(Rf_allocVector(STRSXP, n));
+    for (int i = 0; i < n; i++) SET_STRING_ELT(nm, i, Rf_mkChar(names[i]));
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    *out_names = nm;
+    return out;
+}
+
+/* the series arguments shared by every entry: dimensions and absent-input sentinels */
+typedef struct {
+    int T, p, q, has_u, has_v;
+    const double *u, *v;
+} inputs_t;
+
+static inputs_t get_inputs(SEXP u, SEXP v, int T) {
+    inputs_t in;
+    if (!Rf_isReal(u) || !Rf_isReal(v)) Rf_error("u, v must be double matrices");
+    in.T = T;
+    in.has_u = Rf_ncols(u) > 1;
+    in.has_v = Rf_ncols(v) > 1;
+    in.p = Rf_nrows(u);
+    in.q = Rf_nrows(v);
+    if ((in.has_u && Rf_ncols(u) != T) || (in.has_v && Rf_ncols(v) != T))
+        Rf_error("u, v must have ncol(y) columns");
+    in.u = in.has_u ? REAL(u) : NULL;
+    in.v = in.has_v ? REAL(v) : NULL;
+    return in;
+}
+
+/* named theta list -> packed [A, B(p), C, D(q), Q, R, mu1, V1] */
+static void pack_theta(SEXP th, int p, int q, double *dst) {
+    const int nc[8] = {1, p, 1, q, 1, 1, 1, 1};
+    int o = 0;
+    for (int i = 0; i < 8; i++) {
+        SEXP e = list_get(th, THETA_NAMES[i]);
+        if (!Rf_isReal(e) || Rf_xlength(e) != nc[i]) Rf_error("theta$%s has the wrong length", THETA_NAMES[i]);
+        memcpy(dst + o, REAL(e), sizeof(double) * nc[i]);
+        o += nc[i];
+    }
+}
+
+/* packed theta -> named list of matrices (src/EM.cpp:221-228) */
 static SEXP theta_to_list(const double *th, int p, int q) {
-    static const char *nms[] = {"A", "B", "C", "D", "Q", "R", "mu1", "V1"};
-    const int nc[] = {1, p, 1, q, 1, 1, 1, 1};
-    SEXP out = PROTECT(Rf_allocVector(VECSXP, 8)), names = PROTECT(Rf_allocVector(STRSXP, 8));
+    const int nc[8] = {1, p, 1, q, 1, 1, 1, 1};
+    SEXP nm, out = named_list(8, THETA_NAMES, &nm);
     int o = 0;
     for (int i = 0; i < 8; i++) {
         SET_VECTOR_ELT(out, i, mat(1, nc[i], th + o));
-        SET_STRING_ELT(names, i, Rf_mkChar(nms[i]));
         o += nc[i];
     }
-    Rf_setAttrib(out, R_NamesSymbol, names);
     UNPROTECT(2);
+    return out;
+}
+
+/* list(X, Y, V, J, lik) of src/EM.cpp:126-130 (J may be NULL: propagate, :352-355) */
+static SEXP fit_to_list(int T, const double *X, const double *Y, const double *V, const double *J,
+                        double lik) {
+    static const char *const n5[5] = {"X", "Y", "V", "J", "lik"};
+    static const char *const n4[4] = {"X", "Y", "V", "lik"};
+    SEXP nm, out = named_list(J ? 5 : 4, J ? n5 : n4, &nm);
+    int k = 0;
+    SET_VECTOR_ELT(out, k++, mat(1, T, X));
+    SET_VECTOR_ELT(out, k++, mat(1, T, Y));
+    SET_VECTOR_ELT(out, k++, mat(1, T, V));
+    if (J) SET_VECTOR_ELT(out, k++, mat(1, T, J));
+    SET_VECTOR_ELT(out, k, Rf_ScalarReal(lik));
+    UNPROTECT(2);
+    return out;
+}
+
+/* list(theta, fit, liks, lik, index) -- LDS_EM's return (src/EM.cpp:276-279) + the winner's index */
+static SEXP model_to_list(const inputs_t *in, const double *theta, const double *X, const double *Y,
+                          const double *V, const double *J, const double *liks, int n_iter,
+                          double lik, int index1) {
+    static const char *const nms[5] = {"theta", "fit", "liks", "lik", "index"};
+    SEXP nm, out = named_list(5, nms, &nm);
+    SET_VECTOR_ELT(out, 0, theta_to_list(theta, in->p, in->q));
+    SET_VECTOR_ELT(out, 1, fit_to_list(in->T, X, Y, V, J, lik));
+    SET_VECTOR_ELT(out, 2, mat(n_iter, 1, liks)); /* arma::vec -> n x 1 */
+    SET_VECTOR_ELT(out, 3, Rf_ScalarReal(lik));
+    SET_VECTOR_ELT(out, 4, Rf_ScalarInteger(index1));
+    UNPROTECT(2);
+    return out;
+}
+
+static int *all_devices(int n_cells, int *n_dev) {
+    int n = ldsr_device_count(); /* restarts shard over every GPU of the node, no collective */
+    if (n < 1) Rf_error("ldsrhip: no ROCm device visible");
+    if (n > n_cells) n = n_cells;
+    int *devs = (int *)R_alloc(n, sizeof(int));
+    for (int d = 0; d < n; d++) devs[d] = d;
+    *n_dev = n;
+    return devs;
+}
+
+/* shared body of the batch (one series) and grid (F folds) entries */
+static SEXP em_restart(const double *Y, int F, const inputs_t *in, SEXP *inits, int niter, double tol,
+                       int want_all) {
+    const int T = in->T, p = in->p, q = in->q, P = 6 + p + q;
+    if (niter < 2) Rf_error("niter must be >= 2");
+    int *off = (int *)R_alloc((size_t)F + 1, sizeof(int));
+    off[0] = 0;
+    for (int f = 0; f < F; f++) {
+        const int n = (int)Rf_xlength(inits[f]);
+        if (n < 1) Rf_error("init is empty");
+        off[f + 1] = off[f] + n;
+    }
+    const int n = off[F];
+    double *th0 = (double *)R_alloc((size_t)n * P, sizeof(double));
+    for (int f = 0; f < F; f++)
+        for (int c = off[f]; c < off[f + 1]; c++)
+            pack_theta(VECTOR_ELT(inits[f], c - off[f]), p, q, th0 + (size_t)c * P);
+    double *lik_all = NULL, *theta_all = NULL;
+    int *nit_all = NULL, *st_all = (int *)R_alloc(n, sizeof(int));
+    if (want_all) {
+        theta_all = (double *)R_alloc((size_t)n * P, sizeof(double));
+        lik_all = (double *)R_alloc(n, sizeof(double));
+        nit_all = (int *)R_alloc(n, sizeof(int));
+    }
+    int *winner = (int *)R_alloc(F, sizeof(int)), *nit_w = (int *)R_alloc(F, sizeof(int));
+    double *theta_w = (double *)R_alloc((size_t)F * P, sizeof(double));
+    double *lik_w = (double *)R_alloc(F, sizeof(double));
+    double *liks_w = (double *)R_alloc((size_t)F * niter, sizeof(double));
+    double *X = (double *)R_alloc((size_t)4 * F * T, sizeof(double));
+    double *Yf = X + (size_t)F * T, *V = Yf + (size_t)F * T, *J = V + (size_t)F * T;
+    R_CheckUserInterrupt(); /* the reference polls every 100 iterations (src/EM.cpp:261-262) */
+    int n_dev;
+    int *devs = all_devices(n, &n_dev);
+    const int rc = ldsr_em_restart_grid(n_dev, devs, F, T, p, q, Y, in->u, in->v, 1, off, th0, niter,
+                                        tol, LDSR_ALGO_AUTO, theta_all, lik_all, nit_all, st_all,
+                                        winner, theta_w, lik_w, nit_w, liks_w, X, Yf, V, J);
+    if (rc != LDSR_OK) Rf_error("ldsr_em_restart_grid: %s", ldsr_last_error());
+    for (int c = 0; c < n; c++)
+        if (st_all[c] == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular"); /* arma::inv throws */
+    for (int f = 0; f < F; f++)
+        if (winner[f] < 0) Rf_error("no restart produced a finite likelihood (fold %d)", f + 1);
+
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, F));
+    for (int f = 0; f < F; f++)
+        SET_VECTOR_ELT(out, f, model_to_list(in, theta_w + (size_t)f * P, X + (size_t)f * T,
+                                             Yf + (size_t)f * T, V + (size_t)f * T, J + (size_t)f * T,
+                                             liks_w + (size_t)f * niter, nit_w[f], lik_w[f],
+                                             winner[f] - off[f] + 1));
+    if (want_all) { /* per-restart summary of the single series: list(lik, C, n_iter, status) */
+        static const char *const anm[4] = {"lik", "C", "n_iter", "status"};
+        SEXP nm, all = named_list(4, anm, &nm);
+        SEXP a_lik = PROTECT(Rf_allocVector(REALSXP, n)), a_C = PROTECT(Rf_allocVector(REALSXP, n));
+        SEXP a_it = PROTECT(Rf_allocVector(INTSXP, n)), a_st = PROTECT(Rf_allocVector(INTSXP, n));
+        for (int c = 0; c < n; c++) {
+            REAL(a_lik)[c] = lik_all[c];
+            REAL(a_C)[c] = theta_all[(size_t)c * P + 1 + p];
+            INTEGER(a_it)[c] = nit_all[c];
+            INTEGER(a_st)[c] = st_all[c];
+        }
+        SET_VECTOR_ELT(all, 0, a_lik); SET_VECTOR_ELT(all, 1, a_C);
+        SET_VECTOR_ELT(all, 2, a_it); SET_VECTOR_ELT(all, 3, a_st);
+        /* append `all` to the single model */
+        SEXP m = VECTOR_ELT(out, 0);
+        static const char *const nms[6] = {"theta", "fit", "liks", "lik", "index", "all"};
+        SEXP nm2, m2 = named_list(6, nms, &nm2);
+        for (int i = 0; i < 5; i++) SET_VECTOR_ELT(m2, i, VECTOR_ELT(m, i));
+        SET_VECTOR_ELT(m2, 5, all);
+        SET_VECTOR_ELT(out, 0, m2);
+        UNPROTECT(8);
+    }
+    UNPROTECT(1);
     return out;
 }
 
 /* .Call("ldsrhip_LDS_EM_batch", y, u, v, init, niter, tol):
  * list(theta, fit = list(X, Y, V, J, lik), liks, lik, index, all = list(lik, C, n_iter, status)) */
 SEXP ldsrhip_LDS_EM_batch(SEXP y, SEXP u, SEXP v, SEXP init, SEXP niterS, SEXP tolS) {
-    if (!Rf_isReal(y) || !Rf_isReal(u) || !Rf_isReal(v)) Rf_error("y, u, v must be double matrices");
-    const int T = Rf_ncols(y);
-    const int has_u = Rf_ncols(u) > 1, has_v = Rf_ncols(v) > 1;
-    const int p = Rf_nrows(u), q = Rf_nrows(v), P = 6 + p + q;
-    if ((has_u && Rf_ncols(u) != T) || (has_v && Rf_ncols(v) != T)) Rf_error("u, v must have ncol(y) columns");
-    const int n = (int)Rf_xlength(init), niter = Rf_asInteger(niterS);
-    const double tol = Rf_asReal(tolS);
-    if (n < 1) Rf_error("init is empty");
-    double *th0 = (double *)R_alloc((size_t)n * P, sizeof(double));
-    static const char *nms[] = {"A", "B", "C", "D", "Q", "R", "mu1", "V1"};
-    const int nc[] = {1, p, 1, q, 1, 1, 1, 1};
-    for (int c = 0; c < n; c++) {
-        SEXP th = VECTOR_ELT(init, c);
-        int o = 0;
-        for (int i = 0; i < 8; i++) {
-            SEXP e = list_get(th, nms[i]);
-            if (!Rf_isReal(e) || Rf_xlength(e) != nc[i]) Rf_error("theta$%s has the wrong length", nms[i]);
-            memcpy(th0 + (size_t)c * P + o, REAL(e), sizeof(double) * nc[i]);
-            o += nc[i];
-        }
-    }
-    double *theta = (double *)R_alloc((size_t)n * P, sizeof(double));
-    double *lik = (double *)R_alloc(n, sizeof(double));
-    double *liks = (double *)R_alloc((size_t)n * niter, sizeof(double));
-    int *n_iter = (int *)R_alloc(n, sizeof(int)), *status = (int *)R_alloc(n, sizeof(int));
-    const int off[2] = {0, n};
-    R_CheckUserInterrupt(); /* the reference polls every 100 iterations (src/EM.cpp:261-262) */
-    int n_dev = ldsr_device_count(); /* restarts shard over every GPU of the node, no collective */
-    if (n_dev < 1) Rf_error("ldsrhip: no ROCm device visible");
-    if (n_dev > n) n_dev = n;
-    int *devs = (int *)R_alloc(n_dev, sizeof(int));
-    for (int d = 0; d < n_dev; d++) devs[d] = d;
-    int rc = ldsr_em_batch_multi(n_dev, devs, 1, T, p, q, REAL(y), has_u ? REAL(u) : NULL,
-                                 has_v ? REAL(v) : NULL, 0, off, th0, niter, tol, LDSR_ALGO_AUTO,
-                                 theta, lik, n_iter, status, liks);
-    if (rc != LDSR_OK) Rf_error("ldsr_em_batch_multi: %s", ldsr_last_error());
-    for (int c = 0; c < n; c++)
-        if (status[c] == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular"); /* arma::inv throws */
-    const int k = ldsr_select_restart(n, lik, theta, p, q); /* R/LDS_reconstruction.R:50-58 */
-    if (k < 0) Rf_error("no restart produced a finite likelihood");
-    double *X = (double *)R_alloc((size_t)4 * T, sizeof(double)), *Y = X + T, *V = Y + T, *J = V + T;
-    double flik;
-    rc = ldsr_smooth_batch(0, 1, T, p, q, REAL(y), has_u ? REAL(u) : NULL, has_v ? REAL(v) : NULL, 0,
-                           (const int[]){0, 1}, theta + (size_t)k * P, 1, X, Y, V, J, &flik);
-    if (rc != LDSR_OK) Rf_error("ldsr_smooth_batch: %s", ldsr_last_error());
-
-    SEXP fit = PROTECT(Rf_allocVector(VECSXP, 5)), fn = PROTECT(Rf_allocVector(STRSXP, 5));
-    const char *fnm[] = {"X", "Y", "V", "J", "lik"};
-    const double *fv[] = {X, Y, V, J};
-    for (int i = 0; i < 4; i++) SET_VECTOR_ELT(fit, i, mat(1, T, fv[i]));
-    SET_VECTOR_ELT(fit, 4, Rf_ScalarReal(flik));
-    for (int i = 0; i < 5; i++) SET_STRING_ELT(fn, i, Rf_mkChar(fnm[i]));
-    Rf_setAttrib(fit, R_NamesSymbol, fn);
-
-    SEXP all = PROTECT(Rf_allocVector(VECSXP, 4)), an = PROTECT(Rf_allocVector(STRSXP, 4));
-    SEXP a_lik = PROTECT(Rf_allocVector(REALSXP, n)), a_C = PROTECT(Rf_allocVector(REALSXP, n));
-    SEXP a_it = PROTECT(Rf_allocVector(INTSXP, n)), a_st = PROTECT(Rf_allocVector(INTSXP, n));
-    for (int c = 0; c < n; c++) {
-        REAL(a_lik)[c] = lik[c];
-        REAL(a_C)[c] = theta[(size_t)c * P + 1 + p];
-        INTEGER(a_it)[c] = n_iter[c];
-        INTEGER(a_st)[c] = status[c];
-    }
-    const char *anm[] = {"lik", "C", "n_iter", "status"};
-    SEXP av[] = {a_lik, a_C, a_it, a_st};
-    for (int i = 0; i < 4; i++) { SET_VECTOR_ELT(all, i, av[i]); SET_STRING_ELT(an, i, Rf_mkChar(anm[i])); }
-    Rf_setAttrib(all, R_NamesSymbol, an);
-
-    SEXP out = PROTECT(Rf_allocVector(VECSXP, 6)), on = PROTECT(Rf_allocVector(STRSXP, 6));
-    const char *onm[] = {"theta", "fit", "liks", "lik", "index", "all"};
-    SET_VECTOR_ELT(out, 0, theta_to_list(theta + (size_t)k * P, p, q));
-    SET_VECTOR_ELT(out, 1, fit);
-    SET_VECTOR_ELT(out, 2, mat(n_iter[k], 1, liks + (size_t)k * niter)); /* arma::vec -> n x 1 */
-    SET_VECTOR_ELT(out, 3, Rf_ScalarReal(lik[k]));
-    SET_VECTOR_ELT(out, 4, Rf_ScalarInteger(k + 1));
-    SET_VECTOR_ELT(out, 5, all);
-    for (int i = 0; i < 6; i++) SET_STRING_ELT(on, i, Rf_mkChar(onm[i]));
-    Rf_setAttrib(out, R_NamesSymbol, on);
-    UNPROTECT(10);
+    if (!Rf_isReal(y)) Rf_error("y must be a double matrix");
+    const inputs_t in = get_inputs(u, v, Rf_ncols(y));
+    SEXP res = PROTECT(em_restart(REAL(y), 1, &in, &init, Rf_asInteger(niterS), Rf_asReal(tolS), 1));
+    SEXP out = VECTOR_ELT(res, 0);
+    UNPROTECT(1);
     return out;
+}
+
+/* .Call("ldsrhip_LDS_EM_grid", Y, u, v, inits, niter, tol): Y is T x F (one column per fold),
+ * inits a list of F init lists; returns a list of F models list(theta, fit, liks, lik, index). */
+SEXP ldsrhip_LDS_EM_grid(SEXP Y, SEXP u, SEXP v, SEXP inits, SEXP niterS, SEXP tolS) {
+    if (!Rf_isReal(Y)) Rf_error("Y must be a double matrix (T x folds)");
+    const int F = Rf_ncols(Y);
+    if ((int)Rf_xlength(inits) != F) Rf_error("inits must have one init list per column of Y");
+    const inputs_t in = get_inputs(u, v, Rf_nrows(Y));
+    SEXP *il = (SEXP *)R_alloc(F, sizeof(SEXP));
+    for (int f = 0; f < F; f++) il[f] = VECTOR_ELT(inits, f);
+    return em_restart(REAL(Y), F, &in, il, Rf_asInteger(niterS), Rf_asReal(tolS), 0);
+}
+
+/* .Call("ldsrhip_LDS_EM", y, u, v, theta0, niter, tol)  ==  _ldsr_LDS_EM (src/RcppExports.cpp:40-53) */
+SEXP ldsrhip_LDS_EM(SEXP y, SEXP u, SEXP v, SEXP theta0, SEXP niterS, SEXP tolS) {
+    if (!Rf_isReal(y)) Rf_error("y must be a double matrix");
+    const int T = Rf_ncols(y), niter = Rf_asInteger(niterS);
+    const inputs_t in = get_inputs(u, v, T);
+    const int P = 6 + in.p + in.q, off[2] = {0, 1};
+    if (niter < 2) Rf_error("niter must be >= 2");
+    double *th0 = (double *)R_alloc((size_t)2 * P, sizeof(double)), *th = th0 + P;
+    pack_theta(theta0, in.p, in.q, th0);
+    double *liks = (double *)R_alloc((size_t)niter + 4 * (size_t)T, sizeof(double));
+    double *X = liks + niter, *Y = X + T, *V = Y + T, *J = V + T, lik, flik;
+    int n_iter, status;
+    R_CheckUserInterrupt();
+    int rc = ldsr_em_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th0, niter, Rf_asReal(tolS),
+                           LDSR_ALGO_AUTO, th, &lik, &n_iter, &status, liks);
+    if (rc != LDSR_OK) Rf_error("ldsr_em_batch: %s", ldsr_last_error());
+    if (status == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular");
+    rc = ldsr_smooth_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th, 1, X, Y, V, J, &flik);
+    if (rc != LDSR_OK) Rf_error("ldsr_smooth_batch: %s", ldsr_last_error());
+    SEXP m = PROTECT(model_to_list(&in, th, X, Y, V, J, liks, n_iter, lik, 1));
+    static const char *const nms[4] = {"theta", "fit", "liks", "lik"};
+    SEXP nm, out = named_list(4, nms, &nm);
+    for (int i = 0; i < 4; i++) SET_VECTOR_ELT(out, i, VECTOR_ELT(m, i));
+    UNPROTECT(3);
+    return out;
+}
+
+/* .Call("ldsrhip_Kalman_smoother", y, u, v, theta, stdlik)  ==  _ldsr_Kalman_smoother (:11-24) */
+SEXP ldsrhip_Kalman_smoother(SEXP y, SEXP u, SEXP v, SEXP theta, SEXP stdlikS) {
+    if (!Rf_isReal(y)) Rf_error("y must be a double matrix");
+    const int T = Rf_ncols(y), off[2] = {0, 1};
+    const inputs_t in = get_inputs(u, v, T);
+    double *th = (double *)R_alloc((size_t)(6 + in.p + in.q) + 4 * (size_t)T, sizeof(double));
+    double *X = th + 6 + in.p + in.q, *Y = X + T, *V = Y + T, *J = V + T, lik;
+    pack_theta(theta, in.p, in.q, th);
+    const int rc = ldsr_smooth_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th,
+                                     Rf_asLogical(stdlikS) != 0, X, Y, V, J, &lik);
+    if (rc != LDSR_OK) Rf_error("ldsr_smooth_batch: %s", ldsr_last_error());
+    return fit_to_list(T, X, Y, V, J, lik);
+}
+
+/* .Call("ldsrhip_propagate", theta, u, v, y, stdlik)  ==  _ldsr_propagate (:56-69) */
+SEXP ldsrhip_propagate(SEXP theta, SEXP u, SEXP v, SEXP y, SEXP stdlikS) {
+    if (!Rf_isReal(y)) Rf_error("y must be a double matrix");
+    const int T = Rf_ncols(y), off[2] = {0, 1};
+    const inputs_t in = get_inputs(u, v, T);
+    double *th = (double *)R_alloc((size_t)(6 + in.p + in.q) + 3 * (size_t)T, sizeof(double));
+    double *X = th + 6 + in.p + in.q, *Y = X + T, *V = Y + T, lik;
+    pack_theta(theta, in.p, in.q, th);
+    const int rc = ldsr_propagate_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th,
+                                        Rf_asLogical(stdlikS) != 0, X, Y, V, &lik);
+    if (rc != LDSR_OK) Rf_error("ldsr_propagate_batch: %s", ldsr_last_error());
+    return fit_to_list(T, X, Y, V, NULL, lik);
+}
+
+/* .Call("ldsrhip_Mstep", y, u, v, fit)  ==  _ldsr_Mstep (:26-38) */
+SEXP ldsrhip_Mstep(SEXP y, SEXP u, SEXP v, SEXP fit) {
+    if (!Rf_isReal(y)) Rf_error("y must be a double matrix");
+    const int T = Rf_ncols(y), off[2] = {0, 1};
+    const inputs_t in = get_inputs(u, v, T);
+    SEXP X = list_get(fit, "X"), V = list_get(fit, "V"), J = list_get(fit, "J");
+    if (!Rf_isReal(X) || !Rf_isReal(V) || !Rf_isReal(J) || Rf_xlength(X) != T || Rf_xlength(V) != T ||
+        Rf_xlength(J) != T)
+        Rf_error("fit$X, fit$V, fit$J must be double vectors of length ncol(y)");
+    double *th = (double *)R_alloc((size_t)(6 + in.p + in.q), sizeof(double));
+    int status;
+    const int rc = ldsr_mstep_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, REAL(X), REAL(V),
+                                    REAL(J), th, &status);
+    if (rc != LDSR_OK) Rf_error("ldsr_mstep_batch: %s", ldsr_last_error());
+    if (status == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular");
+    return theta_to_list(th, in.p, in.q);
 }
 
 static const R_CallMethodDef CallEntries[] = {
     {"ldsrhip_LDS_EM_batch", (DL_FUNC)&ldsrhip_LDS_EM_batch, 6},
+    {"ldsrhip_LDS_EM_grid", (DL_FUNC)&ldsrhip_LDS_EM_grid, 6},
+    {"ldsrhip_LDS_EM", (DL_FUNC)&ldsrhip_LDS_EM, 6},
+    {"ldsrhip_Kalman_smoother", (DL_FUNC)&ldsrhip_Kalman_smoother, 5},
+    {"ldsrhip_propagate", (DL_FUNC)&ldsrhip_propagate, 5},
+    {"ldsrhip_Mstep", (DL_FUNC)&ldsrhip_Mstep, 4},
     {NULL, NULL, 0}};
 
 void R_init_ldsrhip(DllInfo *dll) {

@@ -159,6 +159,22 @@ def main():
     nplds = sysd["NPlds"]
     nplds_d = dict(zip(_names(nplds), nplds["value"]))
     fx["NPlds"] = {"theta": _theta(nplds_d["theta"]), "lik": _val(nplds_d["lik"])}
+    # NPcv: the stored result of  cvLDS(NPannual, u, v, start.year = 1600, num.restarts = 20, Z = Z)
+    # with Z = make_Z(NPannual$Qa, nRuns = 30, frac = 0.25, contiguous = TRUE)  (vignettes/ldsr.Rmd:133-139):
+    # the 30 folds (1-based indices into the 46 instrumental years), the cross-validated flows of
+    # every fold, the target, the per-fold metrics and their Tukey-biweight means
+    npcv = dict(zip(_names(sysd["NPcv"]), sysd["NPcv"]["value"]))
+    ycv = _df(npcv["Ycv"])
+    n_inst = len(_df(npcv["target"])["y"])
+    n_rep = len(ycv["Y"]) // n_inst
+    fx["NPcv"] = {
+        "Z": [_val(z) for z in npcv["Z"]],
+        "Ycv": [ycv["Y"][r * n_inst:(r + 1) * n_inst] for r in range(n_rep)],
+        "year": ycv["year"][:n_inst],
+        "target": _df(npcv["target"])["y"],
+        "metrics_dist": _df(npcv["metrics.dist"]),
+        "metrics": {k: v[0] for k, v in _df(npcv["metrics"]).items()},
+    }
     with open(os.path.join(out_dir, "reference_data.json"), "w") as f:
         json.dump(fx, f)
     print("wrote reference_data.json:",

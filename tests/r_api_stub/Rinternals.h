@@ -1,12 +1,15 @@
-/* Minimal DECLARATIONS of the R C API used by ldsr_amd/r_shim/ldsrhip_call.c, for a
- * syntax-only compile check (tests/test_r_shim_syntax.py).  R is not installed in this image;
- * nothing here is linked or run, and this is not a substitute for testing under R. */
+/* Minimal DECLARATIONS of the R C API used by ldsr_amd/r_shim/ldsrhip_call.c.  R is not
+ * installed in this image, so the shim is checked two ways: a syntax-only compile against these
+ * declarations (tests/test_r_shim_syntax.py) and an EXECUTED run against tests/r_mock/rmock.c, a
+ * miniature implementation of exactly these entry points (tests/test_r_shim_mock.py).  Neither
+ * is a substitute for testing under R. */
 #ifndef R_STUB_RINTERNALS_H
 #define R_STUB_RINTERNALS_H
 #include <stddef.h>
 typedef struct SEXPREC *SEXP;
 typedef ptrdiff_t R_xlen_t;
 typedef void *(*DL_FUNC)(void);
+#define LGLSXP 10
 #define REALSXP 14
 #define INTSXP 13
 #define STRSXP 16
@@ -30,6 +33,7 @@ int Rf_ncols(SEXP);
 int Rf_nrows(SEXP);
 int Rf_asInteger(SEXP);
 double Rf_asReal(SEXP);
+int Rf_asLogical(SEXP);
 SEXP Rf_ScalarReal(double);
 SEXP Rf_ScalarInteger(int);
 SEXP Rf_protect(SEXP);
