@@ -35,7 +35,8 @@
 //
 // W > 1 (T > 2048): each wave scans its own 64 lanes exactly as above and the W waves of the
 // cell exchange three small records per iteration through LDS (workgroup = one cell, so plain
-// s_barrier): the wave's forward composite matrix, its reverse affine composite, and its partial
+// s_barrier; the series image is always the global one, so nothing but registers limits how many
+// cells a CU holds): the wave's forward composite matrix, its reverse affine composite, and its partial
 // sums.  Every wave then forms the same totals in the same order, so theta, lik and the stop
 // decision are bit-identical in all waves of the cell.
 //
@@ -187,14 +188,19 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_WIDE_SB      // scheduling barrier after every step of the wide kernels' sweeps
 #define LDSR_WIDE_SB 0
 #endif
+#ifndef LDSR_SCAN_PREFETCH   // one-step software pipeline of the LDS reads in the long-chunk sweeps
+#define LDSR_SCAN_PREFETCH 0  // (same-box A/B on cfg4: 10.72 ms with, 10.40 ms without -- off)
+#endif
 __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_OCC1 && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
 
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT>
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
-                                             const double *us, const double *vs, double *xch,
+                                             __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp);
 
 // QUEUE = waves pull cells from the per-series work queue (cells converge at different
@@ -205,7 +211,6 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 template <int PP, int QQ, int L, int W, bool QUEUE, bool GIMG, bool FIT>
 __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(EmParams prm) {
     extern __shared__ double smem[];
-    constexpr int NL = 64 * W;
     constexpr long IMG = scan_image_doubles(L, W, PP, QQ);
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
@@ -227,14 +232,14 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
         if constexpr (W > 1) xch = smem + IMG;
         __syncthreads();
     }
-    const double *us = ys + NL * L;          // [L][PP][NL]
-    const double *vs = us + NL * L * PP;     // [L][QQ][NL]
+    // global image: buffer resource over the series image (out-of-range reads return 0)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gimg, 0, (int)(IMG * sizeof(double)), 0x00020000);
     const bool dense = prm.sc[s].n_obs == T && !FIT && W == 1;   // FIT / multi-wave: generic path only
     if constexpr (W > 1) {
         // one group: every wave of the workgroup works on the same cell
         int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
         if constexpr (!QUEUE) {
-            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT>(prm, ys, us, vs, xch, s, c0, lane, wave, nl, rp);
+            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0, lane, wave, nl, rp);
         } else {
             for (int pulls = 0; pulls <= nc; pulls++) {
                 if (threadIdx.x == 0) *qslot = atomicAdd(prm.queue + s, 1);
@@ -242,15 +247,15 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
                 const int k = __builtin_amdgcn_readfirstlane(*(volatile int *)qslot);
                 __syncthreads();              // everyone has read the slot before the next pull
                 if (k >= nc) break;
-                em_scan_cell<PP, QQ, L, W, false, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, wave, nl, rp);
+                em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, wave, nl, rp);
             }
         }
     } else if constexpr (!QUEUE) {
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
         if (dense)
-            em_scan_cell<PP, QQ, L, 1, true, FIT>(prm, ys, us, vs, xch, s, c0 + wave, lane, 0, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp);
         else
-            em_scan_cell<PP, QQ, L, 1, false, FIT>(prm, ys, us, vs, xch, s, c0 + wave, lane, 0, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp);
     } else {
         // Work queue: every wave pulls cells of this series until the counter passes the
         // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
@@ -263,25 +268,39 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
             if (dense)
-                em_scan_cell<PP, QQ, L, 1, true, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, 0, nl, rp);
+                em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp);
             else
-                em_scan_cell<PP, QQ, L, 1, false, FIT>(prm, ys, us, vs, xch, s, c0 + k, lane, 0, nl, rp);
+                em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp);
         }
     }
 }
 
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
 __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
-                                             const double *us, const double *vs, double *xch,
+                                             __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp) {
     constexpr int NL = 64 * W;
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
     const int vl = wv * 64 + lane;            // virtual lane
     // element (step j, row k) of this lane's chunk of y / u / v
-    auto Yat = [&](int j) { return ys[j * NL + vl]; };
-    auto Uat = [&](int j, int k) { return us[(j * PP + k) * NL + vl]; };
-    auto Vat = [&](int j, int k) { return vs[(j * QQ + k) * NL + vl]; };
+    // LDS image: (row pointer)[lane].  Global image: raw buffer loads -- ONE VGPR holds the lane's
+    // byte offset and the row offset travels in the scalar soffset operand (plain global loads
+    // made the compiler keep a 64-bit address pair per 4 KiB window and spill ~400 VGPRs).
+    const unsigned uvl = (unsigned)vl;
+    const double *us = ys + NL * L;          // LDS image: [L][PP][NL] (own base: 64 KiB ds offsets)
+    const double *vs = us + NL * L * PP;     //            [L][QQ][NL]
+    auto img_at = [&](const double *base, int base_elem, int elem) -> double {
+        if constexpr (GIMG) {
+            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(uvl * 8u), (base_elem + elem) * 8, 0);
+            return __hiloint2double((int)w.y, (int)w.x);
+        } else {
+            return (base + elem)[uvl];
+        }
+    };
+    auto Yat = [&](int j) { return img_at(ys, 0, j * NL); };
+    auto Uat = [&](int j, int k) { return img_at(us, NL * L, (j * PP + k) * NL); };
+    auto Vat = [&](int j, int k) { return img_at(vs, NL * L * (1 + PP), (j * QQ + k) * NL); };
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
@@ -462,9 +481,22 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         double r0 = fast_rcp(sg);
         const double Xp0 = Xp, Vp0 = Vp, sg0 = sg, r00 = r0;   // entry state (re-run of [0, HS))
         double Pi = 1.0, G = 0.0, H = 0.0;                     // reverse composite (HS > 0 only)
+        // Long chunks end every step with a scheduling barrier (register pressure), which would
+        // also pin each step's LDS reads right before their use: software-pipeline them one step
+        // ahead instead (PF) -- the reads of step j+1 are issued at the top of step j.
+        constexpr bool PF = L > 16 && !EBR && LDSR_SCAN_PREFETCH;
+        double e_nx = 0.0, bu_nx = 0.0;
+        if (PF && act) { e_nx = e_at(0); bu_nx = bu_at(0); }
         auto f2 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double e = EBR ? ev[j] : e_at(j), bu = EBR ? buv[j] : bu_at(j);
+            double e, bu;
+            if constexpr (PF) {
+                e = e_nx; bu = bu_nx;
+                if (j + 1 < L) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
+            } else {
+                e = EBR ? ev[j] : e_at(j);
+                bu = EBR ? buv[j] : bu_at(j);
+            }
             const double r = o ? r0 : 0.0;             // 1/Sigma_t; 0 = "no update" (:82-84)
             const double sl = o ? sg : 1.0;
             sprod *= sl;
@@ -662,9 +694,17 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             // re-run the forward recursion of steps [0, HS) from the lane's entry state; the
             // likelihood terms of these steps were already accumulated in F2
             double Xq = Xp0, Vq = Vp0, sgq = sg0, rq = r00;
+            if (PF && act) { e_nx = e_at(0); bu_nx = bu_at(0); }
             auto f2r = [&](int j) {
                 const bool o = DENSE || ((obsmask >> j) & 1u);
-                const double e = EBR ? ev[j] : e_at(j), bu = EBR ? buv[j] : bu_at(j);
+                double e, bu;
+                if constexpr (PF) {
+                    e = e_nx; bu = bu_nx;
+                    if (j + 1 < HS) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
+                } else {
+                    e = EBR ? ev[j] : e_at(j);
+                    bu = EBR ? buv[j] : bu_at(j);
+                }
                 const double r = o ? rq : 0.0;
                 const double w = Vq * r;
                 const double K = C * w;

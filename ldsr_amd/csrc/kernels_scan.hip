@@ -40,11 +40,11 @@ ScanPlan scan_plan(int T, int PP, int QQ) {
     }
     if (!p.L) return p;
     const size_t lds = (size_t)(scan_image_doubles(p.L, p.W, PP, QQ) + scan_xch_doubles(p.W)) * sizeof(double);
-    // the image is read from global memory when it does not fit a CU's LDS (L >= 20 only: the
-    // short-chunk images always fit); four-wave cells are compiled in that form only
-    size_t lim = kLdsBytes;
-    if (const char *e = getenv("LDSR_SCAN_LDS_IMAGE_MAX_BYTES")) lim = (size_t)strtoull(e, nullptr, 10);
-    p.gimg = p.L >= 20 && (p.W == 4 || lds > kLdsBytes || (p.W == 2 && lds > lim));
+    // the image is read from global memory (raw buffer loads, L2 / L1 resident) when it does not
+    // fit a CU's LDS (L >= 20 only: the short-chunk images always fit) and for every multi-wave
+    // cell: one cell per workgroup would let an LDS image cap a CU at one or two cells, while the
+    // global image leaves 4 (W = 2) or 2 (W = 4) cells per CU -- measured 1.5x faster at W = 2
+    p.gimg = p.L >= 20 && (p.W > 1 || lds > kLdsBytes);
     if (!p.gimg && lds > kLdsBytes) return p;
     p.cpb = p.W > 1 ? 1 : (p.gimg ? 4 : scan_wpb(p.L, PP, QQ));   // GIMG: two workgroups per CU by VGPRs
     p.ok = true;

@@ -48,19 +48,6 @@ def test_long_series_on_the_multi_wave_scan_kernel(T, p, q, mask):
     assert parity_close(r0["liks"][:, -1], ref0[1], RTOL, ATOL)
 
 
-def test_two_wave_cells_global_image_equals_lds_image(monkeypatch):
-    """W = 2 exists with the series image in LDS and in global memory; both give the same bits."""
-    import ldsr_amd
-    from ldsr_amd import synth
-    y, u, v = synth.make_series(3000, 1, 2, series_id=78, mask="paleo")
-    th0 = synth.make_init_packed(1, 2, 6, seed=10)
-    a = ldsr_amd.em_batch(y, u, v, th0, niter=25, tol=1e-5, algo=SCAN)
-    monkeypatch.setenv("LDSR_SCAN_LDS_IMAGE_MAX_BYTES", "0")
-    b = ldsr_amd.em_batch(y, u, v, th0, niter=25, tol=1e-5, algo=SCAN)
-    for k in ("theta", "lik", "n_iter", "status"):
-        assert np.array_equal(a[k], b[k]), k
-
-
 def test_long_series_multi_series_grid_and_winner_fit():
     """Several long series with own inputs through the one-call restart entry: the multi-wave
     kernel under the work queue, then the FIT form for the winners."""
