@@ -267,7 +267,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["custom"])
+    ap.add_argument("--shape", default=None, help="custom workload: T,p,q,restarts (one series, weak scaling)")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan")
     ap.add_argument("--mask", default="dense", choices=["dense", "paleo"])
     ap.add_argument("--niter", type=int, default=None, help="EM iteration cap (default: the workload's 100)")
@@ -308,6 +309,9 @@ def main():
     from ldsr_amd import _lib
     L = _lib.lib()
 
+    if args.workload == "custom":     # diagnostics only (kernel studies); never the reported metric
+        cT, cp, cq, cr = [int(x) for x in args.shape.split(",")]
+        WORKLOADS["custom"] = dict(T=cT, p=cp, q=cq, series=1, restarts=cr, niter=100, scaling="weak")
     w = WORKLOADS[args.workload]
     T, p, q, niter = w["T"], w["p"], w["q"], (args.niter or w["niter"])
     single = w["series"] == 1

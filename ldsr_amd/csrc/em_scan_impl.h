@@ -816,7 +816,11 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         bool stop = it >= prm.niter;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
+#ifdef LDSR_SC_PLAIN     // A/B switch: the round-1 form (vector loads through a plain pointer)
         mstep_update<PP, QQ, true>(th, S, sc, T);
+#else
+        mstep_update<PP, QQ, true>(th, S, (SeriesConstK)sc, T);
+#endif
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
         th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);

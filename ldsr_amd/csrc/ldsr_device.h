@@ -95,9 +95,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
 //   zu = Tuu^{-1} Tux,   A = (Tx1x - Tx1u zu) / (Txx - Txu zu), B = Tuu^{-1} Tx1u' - A zu
 // R uses the algebraic form of ((y - yhat) y')/n  (:177) and Q is the reference's (:210).
 // FAST: the four divisions become multiplications by rcp+Newton reciprocals (scan kernel).
-template <int PP, int QQ, bool FAST = false>
-__device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, QQ> &S,
-                                             const SeriesConst *__restrict__ sc, int T) {
+// SCP: pointer to the per-series constants.  The scan kernel passes a constant-address-space
+// pointer (SeriesConstK): the record is written by series_prep_kernel before the EM kernel starts
+// and never changes, and only loads from that address space are scalarised -- s_load into SGPRs,
+// many in flight -- inside a loop that also stores to global memory.  Through a plain pointer
+// they became vector loads waited for pair by pair: 8 (q = 4) to 40 (p = 4, q = 8) dependent
+// L2 round trips per EM iteration.
+typedef const __attribute__((address_space(4))) SeriesConst *SeriesConstK;
+
+template <int PP, int QQ, bool FAST = false, typename SCP = const SeriesConst *>
+__device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, QQ> &S, SCP sc, int T) {
     double zv[QQ];
 #pragma unroll
     for (int k = 0; k < QQ; k++) {
