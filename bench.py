@@ -404,8 +404,13 @@ def main():
                 roof["valu_insts_per_unit"] = pmc["valu_insts_per_unit"]
                 roof["issue_frac"] = (pmc["valu_insts_per_unit"] * units_rank / kern_s
                                       / (N_SIMD * CLOCK_HZ / 4.0))
-            if pmc.get("valu_busy_frac") is not None:
-                roof["valu_busy_frac"] = pmc["valu_busy_frac"]
+            if pmc.get("fp64_flops_executed_per_unit"):
+                # what the kernel actually executes (FMA = 2 flops, counted by the SQ): the
+                # parallel-in-time formulation does ~1.9x the algorithmic flops
+                roof["fp64_executed_tflops"] = pmc["fp64_flops_executed_per_unit"] * units_rank / kern_s / 1e12
+                roof["fp64_executed_frac"] = roof["fp64_executed_tflops"] / FP64_VALU_PEAK_TFLOPS
+            if pmc.get("valu_active_per_wave_cycle") is not None:
+                roof["valu_busy_frac"] = 2.0 * pmc["valu_active_per_wave_cycle"]   # two waves per SIMD
         out = {
             "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
             "value": value, "unit": "restart*EM-iter/s", "n_gpus": world, "steps": args.steps,

@@ -5,9 +5,9 @@
 // owns L (the first rp lanes) or L-1 consecutive time steps, so only the last step of a chunk is
 // predicated.  All per-step state lives in that lane's registers and nothing but the final theta
 // / lik / n_iter / status ever goes to HBM.  The series (y, u, v) comes as a chunk-transposed
-// image [j][k][virtual lane] built once per launch by series_prep_kernel; the kernel copies it
-// into LDS (flat coalesced copy; the 64 lanes of a wave then read consecutive 8-byte words:
-// conflict-free ds_read_b64) or, when it exceeds the 160 KiB of a CU (GIMG), reads the very same
+// image [step][value pair][virtual lane][2] built once per launch by series_prep_kernel; the
+// kernel copies it into LDS (flat coalesced copy; the 64 lanes of a wave then read consecutive
+// 16-byte words: conflict-free ds_read_b128) or, when it exceeds the 160 KiB of a CU (GIMG), reads the very same
 // layout straight from global memory (coalesced 512-byte rows, L2 resident).
 //
 // The reference recursions (/root/reference/src/EM.cpp:70-104) are strictly sequential in t.
@@ -167,10 +167,16 @@ __device__ __forceinline__ PMat pdpp(const PMat &m) {
 // straight-line code.  Virtual lane l starts at t0 = l*(L-1) + min(l, rp).  Requires
 // L*(L-1) <= T <= NL*L (see scan_plan in kernels_scan.hip).
 //
-// Series image (doubles): y [L][NL] (0 where missing / unused), then u [L][PP][NL] (zero for
-// t = T-1), then v [L][QQ][NL]; element (step j, row k) of virtual lane l at [(j*K + k)*NL + l].
+// Series image: the K = 1 + PP + QQ values of one time step -- value 0 = y (0 where missing /
+// unused), values 1..PP = u (zero for t = T-1), values 1+PP.. = v -- are stored in PAIRS, 16 bytes
+// per lane: pair m of step j of virtual lane l at doubles [((j*KP + m)*NL + l)*2 + {0,1}],
+// KP = ceil(K/2) (an odd K leaves the last half-pair zero).  Two values then come with ONE
+// ds_read_b128 (4 LDS cycles per wave) where two separate 8-byte rows were fused by the
+// compiler into ds_read2st64_b64 (8 cycles): the LDS pipe, shared by the 8 waves of a CU, was
+// 65-85 % busy with those.
+__host__ __device__ constexpr int scan_pairs(int PP, int QQ) { return (1 + PP + QQ + 1) / 2; }
 __host__ __device__ constexpr long scan_image_doubles(int L, int W, int PP, int QQ) {
-    return (long)64 * W * L * (1 + PP + QQ);
+    return (long)64 * W * L * 2 * scan_pairs(PP, QQ);
 }
 // per-wave exchange records of a multi-wave cell (doubles): forward composite (8), reverse
 // composite (4), partial sums (XCH_SUMS), plus one slot for the queue pull
@@ -210,7 +216,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 // W > 1: the workgroup is ONE group of W waves working on one cell at a time.
 template <int PP, int QQ, int L, int W, bool QUEUE, bool GIMG, bool FIT>
 __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(EmParams prm) {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr long IMG = scan_image_doubles(L, W, PP, QQ);
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
@@ -284,23 +290,22 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     constexpr bool SB = scan_sb(PP, QQ);
     const int vl = wv * 64 + lane;            // virtual lane
     // element (step j, row k) of this lane's chunk of y / u / v
-    // LDS image: (row pointer)[lane].  Global image: raw buffer loads -- ONE VGPR holds the lane's
-    // byte offset and the row offset travels in the scalar soffset operand (plain global loads
-    // made the compiler keep a 64-bit address pair per 4 KiB window and spill ~400 VGPRs).
-    const unsigned uvl = (unsigned)vl;
-    const double *us = ys + NL * L;          // LDS image: [L][PP][NL] (own base: 64 KiB ds offsets)
-    const double *vs = us + NL * L * PP;     //            [L][QQ][NL]
-    auto img_at = [&](const double *base, int base_elem, int elem) -> double {
+    // value i of step j of this lane (0 = y, 1.. = u, 1+PP.. = v): see the image layout above.
+    // Global image: raw buffer loads -- ONE VGPR holds the lane's byte offset and the pair offset
+    // travels in the scalar soffset operand (plain global loads made the compiler keep a 64-bit
+    // address pair per 4 KiB window and spill ~400 VGPRs).
+    constexpr int KP = scan_pairs(PP, QQ);
+    auto val = [&](int j, int i) -> double {
         if constexpr (GIMG) {
-            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(uvl * 8u), (base_elem + elem) * 8, 0);
+            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, vl * 16, (((j * KP + (i >> 1)) * NL) * 2 + (i & 1)) * 8, 0);
             return __hiloint2double((int)w.y, (int)w.x);
         } else {
-            return (base + elem)[uvl];
+            return ys[((j * KP + (i >> 1)) * NL + vl) * 2 + (i & 1)];
         }
     };
-    auto Yat = [&](int j) { return img_at(ys, 0, j * NL); };
-    auto Uat = [&](int j, int k) { return img_at(us, NL * L, (j * PP + k) * NL); };
-    auto Vat = [&](int j, int k) { return img_at(vs, NL * L * (1 + PP), (j * QQ + k) * NL); };
+    auto Yat = [&](int j) { return val(j, 0); };
+    auto Uat = [&](int j, int k) { return val(j, 1 + k); };
+    auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;

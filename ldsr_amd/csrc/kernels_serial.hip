@@ -102,30 +102,31 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
         }
     }
     if (prm.img) {
-        // chunk-transposed image of the scan kernel (layout: em_scan_impl.h): element (step j,
-        // row k) of virtual lane l at [(j*K + k)*NL + l]; 0 where missing / beyond the chunk
+        // chunk-transposed image of the scan kernel (layout: em_scan_impl.h): the K = 1+PP+QQ
+        // values of a step in pairs, pair m of step j of virtual lane l at
+        // [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where missing / beyond the chunk / padding
         double *im = prm.img + (long)s * prm.img_stride;
-        const int L = prm.L, NL = prm.NL;
+        const int L = prm.L, NL = prm.NL, K = 1 + PP + QQ, KP = (K + 1) / 2;
         const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
-        for (int i = tid; i < NL * L; i += 256) {
-            const int j = i / NL, l = i - j * NL, t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            const double yv = ok ? y[t] : 0.0;
-            im[i] = isfinite(yv) ? yv : 0.0;
-        }
-        double *imu = im + (long)NL * L;
-        for (int i = tid; i < NL * L * PP; i += 256) {
-            const int l = i % NL, jk = i / NL, j = jk / PP, k = jk - j * PP;
+        for (int e = tid; e < NL * L * KP * 2; e += 256) {
+            const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
+            const int i = 2 * m + h;
             const int t = l * (L - 1) + min(l, rp) + j;
             const bool ok = l < nl && (j < L - 1 || l < rp);
-            imu[i] = (ok && u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
-        }
-        double *imv = imu + (long)NL * L * PP;
-        for (int i = tid; i < NL * L * QQ; i += 256) {
-            const int l = i % NL, jk = i / NL, j = jk / QQ, k = jk - j * QQ;
-            const int t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            imv[i] = (ok && v && k < q) ? v[(long)t * q + k] : 0.0;
+            double val = 0.0;
+            if (ok) {
+                if (i == 0) {
+                    const double yv = y[t];
+                    val = isfinite(yv) ? yv : 0.0;
+                } else if (i <= PP) {
+                    const int k = i - 1;
+                    val = (u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
+                } else if (i < K) {
+                    const int k = i - 1 - PP;
+                    val = (v && k < q) ? v[(long)t * q + k] : 0.0;
+                }
+            }
+            im[e] = val;
         }
     }
     // identity / zero padding of the statistics

@@ -12,6 +12,7 @@ for w in cfg2 cfg3 cfg4 cfg5; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/write.err
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/sq -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/sq.err
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/sq2 -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/sq2.err
+  rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS --output-format csv -d $out/sq3 -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/sq3.err
   python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $out/bench.json 2> $out/bench.err
   echo "$w done: $(ls $out)"
 done

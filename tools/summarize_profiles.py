@@ -69,7 +69,7 @@ def main():
         json.dump(bench, open(os.path.join(prof, "%s_%s_bench.json" % (rnd, w)), "w"))
         json.dump(under, open(os.path.join(prof, "%s_%s_bench_under_rocprof.json" % (rnd, w)), "w"))
         vals = {}
-        for sub in ("fetch", "write", "sq", "sq2"):
+        for sub in ("fetch", "write", "sq", "sq2", "sq3"):
             rows = counter_rows(os.path.join(wdir, sub))
             v, _ = per_kernel(rows, kernel.split("<")[0])
             vals.update(v)
@@ -90,6 +90,15 @@ def main():
             "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
             "valu_insts_per_unit": vals.get("SQ_INSTS_VALU", 0.0) / units,
             "lds_insts_per_unit": vals.get("SQ_INSTS_LDS", 0.0) / units,
+            # executed fp64 arithmetic: wave instructions x 64 lanes, an FMA counts two flops
+            "fp64_insts_per_unit": {k: vals.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) / units
+                                    for k in ("FMA", "MUL", "ADD", "TRANS")},
+            "fp64_flops_executed_per_unit": 64.0 * (2 * vals.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+                                                    + vals.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                                                    + vals.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                                                    + vals.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) / units,
+            "lds_issue_stall_per_wave_cycle": (vals["SQ_WAIT_INST_LDS"] / vals["SQ_WAVE_CYCLES"])
+            if vals.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_LDS" in vals else None,
             "waves": vals.get("SQ_WAVES"),
             "valu_active_per_wave_cycle": (vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"])
             if vals.get("SQ_WAVE_CYCLES") else None,
@@ -102,7 +111,8 @@ def main():
             "bench_kernel_ms_same_command": under["roofline"]["kernel_ms"],
             "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
             "source": ["profiles/%s_%s_%s" % (rnd, w, s) for s in
-                       ("kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "pmc_sq.csv", "pmc_sq2.csv")],
+                       ("kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "pmc_sq.csv", "pmc_sq2.csv",
+                        "pmc_sq3.csv")],
         }
         entries.append(e)
         print(w, kernel, "rocprof %.3f ms, bench (same command) %.3f ms, unprofiled %.3f ms; VALU/unit %.0f, "
