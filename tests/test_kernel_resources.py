@@ -1,0 +1,29 @@
+"""Register budget of the scan kernels that run BASELINE's T=1000 configs (compile-time check,
+no GPU): the config-2 kernels must stay free of scratch at two waves per SIMD -- a refactor of
+the LDS accessors once cost them 70 spilled VGPRs without any test noticing -- and the wide
+config-3 kernel must not spill more than it does today.  Parses hipcc's
+-Rpass-analysis=kernel-resource-usage through tools/resource_usage.py (~1 min)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_scan_kernel_register_budget():
+    import resource_usage
+    rows = {r[0]: r for r in resource_usage.table(os.path.join(ROOT, "ldsr_amd", "csrc", "em_scan_L16.hip"))}
+    assert len(rows) == 48      # 16 padded (p, q) shapes x {static, queue, FIT}
+
+    def get(name):
+        (k,) = [k for k in rows if name in k]
+        _, vgpr, agpr, vspill, scratch, occ, sgpr, sspill = rows[k]
+        return vgpr, vspill, scratch, occ
+
+    for tmpl in ("<1, 2, 16, 1, false, false, false>", "<1, 2, 16, 1, true, false, false>",
+                 "<1, 4, 16, 1, false, false, false>", "<1, 1, 16, 1, false, false, false>",
+                 "<2, 2, 16, 1, false, false, false>"):
+        vgpr, vspill, scratch, occ = get(tmpl)
+        assert (vspill, scratch, occ) == (0, 0, 2) and vgpr <= 256, (tmpl, vgpr, vspill, scratch, occ)
+    vgpr, vspill, scratch, occ = get("<4, 8, 16, 1, false, false, false>")      # config 3
+    assert occ == 2 and scratch <= 64, (vgpr, vspill, scratch, occ)
