@@ -1,5 +1,5 @@
 """Randomized GPU-vs-oracle parity fuzz (run on the GPU box):  python tools/fuzz_parity.py [n] [seed]
-Random T (2..2048), p, q (1..8, sometimes absent), NA patterns, 1..5 series with own or shared
+Random T (2..8192: one, two and four waves per cell), p, q (1..8, sometimes absent), NA patterns, 1..5 series with own or shared
 inputs, ragged cell counts, niter / tol; serial kernel and AUTO (= scan kernel when supported).  Prints one line per failing case and a
 summary; exit status 1 if anything failed."""
 import os
@@ -24,7 +24,7 @@ def main():
     bad = 0
     for case in range(n):
         T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 300), rng.integers(300, 1100),
-                            rng.integers(1100, 2049)]))
+                            rng.integers(1100, 2049), rng.integers(2049, 4097), rng.integers(4097, 8193)]))
         p, q = int(rng.integers(1, 9)), int(rng.integers(1, 9))
         S = int(rng.integers(1, 6))
         shared = bool(rng.integers(0, 2)) and S > 1
@@ -56,7 +56,7 @@ def main():
         counts[int(rng.integers(0, S))] += 1
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         th0 = synth.make_init_packed(pe, qe, int(off[-1]), seed=int(rng.integers(0, 10 ** 6)))
-        niter = int(rng.choice([2, 3, 10, 60, 200]))
+        niter = int(rng.choice([2, 3, 10, 60, 200] if T <= 2048 else [2, 3, 10, 40]))
         tol = float(rng.choice([0.0, 1e-5, 1e-3]))
         soc = np.repeat(np.arange(S), counts).astype(np.int32)
 
