@@ -69,11 +69,13 @@ extern "C" {
 #define LDSR_EINVAL 1        /* bad argument */
 #define LDSR_EUNSUPPORTED 2  /* p or q above the compiled limit */
 #define LDSR_EHIP 3          /* a HIP runtime call failed (no device, OOM, launch error) */
+#define LDSR_EINTERRUPTED 4  /* the interrupt callback asked to stop; outputs are incomplete */
 
 /* per-cell status words */
 #define LDSR_CELL_OK 0
 #define LDSR_CELL_NONFINITE 1 /* final lik is NaN/Inf (tolerated by the reference's selection, na.rm) */
 #define LDSR_CELL_SINGULAR 2  /* Svv or Tuu of the series is singular: arma::inv would throw */
+#define LDSR_CELL_INTERRUPTED 3 /* stopped early by the interrupt callback (theta = last E-step's) */
 
 /* algorithm selector */
 #define LDSR_ALGO_AUTO 0
@@ -188,6 +190,16 @@ int ldsr_penalized_lik_batch(int device, int n_series, int T, int p, int q, cons
                              const double *u, const double *v, int shared_uv,
                              const int *cell_offsets, const double *theta, double lambda,
                              double *pl);
+
+/* User interrupts during a run (the reference calls Rcpp::checkUserInterrupt() every 100 EM
+ * iterations, src/EM.cpp:261-262).  While a callback is registered, the thread that called an
+ * EM entry point (ldsr_em_batch[_multi], ldsr_em_restart_grid / _groups) invokes it about once
+ * per millisecond while it waits for the device -- never from the library's worker threads; a
+ * non-zero return raises a host-pinned flag that every running EM kernel polls every 64
+ * iterations: cells stop with status LDSR_CELL_INTERRUPTED and the call returns
+ * LDSR_EINTERRUPTED.  NULL unregisters.  The R shim registers R_CheckUserInterrupt wrapped in
+ * R_ToplevelExec. */
+int ldsr_set_interrupt_callback(int (*callback)(void *), void *arg);
 
 /* Optional kernel timer.  While enabled, every ldsr_em_batch_device call brackets its EM
  * kernel with HIP events on the launch stream; collect() waits for them and returns the summed

@@ -269,12 +269,16 @@ def em_restart_grid(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, de
     return out
 
 
-def ensemble_restart(y, members, inits, niter=1000, tol=1e-5, devices=(0,), algo=ALGO_AUTO):
+def ensemble_restart(y, members, inits, niter=1000, tol=1e-5, devices=(0,), algo=ALGO_AUTO,
+                     cell_offsets=None):
     """The ensemble loop of LDS_reconstruction (R/LDS_reconstruction.R:242-246): `members` is a
     list of (u, v) pairs that may differ in p and q (tests/testthat/test-ensemble.R:4-5),
     `inits` the matching list of packed theta0 arrays [n_restarts, 6+p+q].  All members run
     concurrently inside ONE library call (ldsr_em_restart_groups); returns one
-    em_restart_grid-style dict per member."""
+    em_restart_grid-style dict per member.  y may hold several series / CV folds [S, T]
+    (the nested fold x member loop of cvLDS, R/LDS_reconstruction.R:377-381): every member then
+    runs the whole grid, with `cell_offsets` [S+1] (shared by the members; default: equal
+    split of each member's restarts over the series)."""
     import ctypes as C
     if len(members) != len(inits):
         raise ValueError("members and inits must have the same length")
@@ -288,9 +292,14 @@ def ensemble_restart(y, members, inits, niter=1000, tol=1e-5, devices=(0,), algo
         if th0.ndim != 2 or th0.shape[1] != P:
             raise ValueError("inits[%d] must be [n, %d]" % (g, P))
         n = th0.shape[0]
-        off = np.array([0, n], dtype=np.int32) if S == 1 else None
-        if off is None:
-            raise ValueError("ensemble members share one y series")
+        if cell_offsets is not None:
+            off = np.ascontiguousarray(cell_offsets, dtype=np.int32)
+        elif n % S == 0:
+            off = (np.arange(S + 1) * (n // S)).astype(np.int32)
+        else:
+            raise ValueError("inits[%d]: %d restarts do not split evenly over %d series" % (g, n, S))
+        if off.size != S + 1 or off[-1] != n:
+            raise ValueError("cell_offsets must have S+1 entries ending at every member's restart count")
         out, allr = _grid_outputs(S, T, P, n, int(niter), True)
         keep.append((Y, U, V, th0, off))
         outs.append((out, allr))

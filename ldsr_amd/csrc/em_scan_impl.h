@@ -138,6 +138,17 @@ __device__ __forceinline__ double dppd(double old, double src) {
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+#ifndef LDSR_DPP_BOUND_CTRL  // zero-identity scan operands through bound_ctrl (no `old` initialisation)
+#define LDSR_DPP_BOUND_CTRL 1
+#endif
+// Same with zero as the out-of-range value: bound_ctrl makes the hardware supply the 0, so no
+// `old` register has to be initialised first (full row / bank masks only).
+template <int CTRL>
+__device__ __forceinline__ double dppz(double src) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 #define DPP_ROW_SHL(n) (0x100 + (n))
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_WAVE_SHL1 0x130
@@ -150,12 +161,19 @@ template <int CTRL, int RM>
 __device__ __forceinline__ PMat pdpp(const PMat &m) {
     PMat r;
     r.m00 = dppd<CTRL, RM>(1.0, m.m00);
-    r.m01 = dppd<CTRL, RM>(0.0, m.m01);
-    r.m10 = dppd<CTRL, RM>(0.0, m.m10);
     r.m11 = dppd<CTRL, RM>(1.0, m.m11);
-    r.m20 = dppd<CTRL, RM>(0.0, m.m20);
-    r.m21 = dppd<CTRL, RM>(0.0, m.m21);
     r.m22 = dppd<CTRL, RM>(1.0, m.m22);
+    if constexpr (RM == 0xF && LDSR_DPP_BOUND_CTRL) {     // zero entries: hardware-supplied 0
+        r.m01 = dppz<CTRL>(m.m01);
+        r.m10 = dppz<CTRL>(m.m10);
+        r.m20 = dppz<CTRL>(m.m20);
+        r.m21 = dppz<CTRL>(m.m21);
+    } else {
+        r.m01 = dppd<CTRL, RM>(0.0, m.m01);
+        r.m10 = dppd<CTRL, RM>(0.0, m.m10);
+        r.m20 = dppd<CTRL, RM>(0.0, m.m20);
+        r.m21 = dppd<CTRL, RM>(0.0, m.m21);
+    }
     return r;
 }
 
@@ -360,6 +378,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
+    bool interrupted = false;   // the host raised the interrupt flag (src/EM.cpp:261-262 polls too)
     // Per-step (J_t, g_t, h_t) kept in registers between the forward and the backward sweep.
     // Chunks longer than 16 steps (T > 1024) would need more than 256 VGPRs and drop to one
     // wave per SIMD, so for them only the second half [HS, L) is kept; the reverse composite is
@@ -633,8 +652,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 #define RSCAN_ROUND(n)                                                     \
         {                                                                  \
             const double Pb = dppd<DPP_ROW_SHL(n), 0xF>(1.0, Pi);          \
-            const double Gb = dppd<DPP_ROW_SHL(n), 0xF>(0.0, G);           \
-            const double Hb = dppd<DPP_ROW_SHL(n), 0xF>(0.0, H);           \
+            const double Gb = LDSR_DPP_BOUND_CTRL ? dppz<DPP_ROW_SHL(n)>(G) : dppd<DPP_ROW_SHL(n), 0xF>(0.0, G); \
+            const double Hb = LDSR_DPP_BOUND_CTRL ? dppz<DPP_ROW_SHL(n)>(H) : dppd<DPP_ROW_SHL(n), 0xF>(0.0, H); \
             G = fma(Pi, Gb, G);                                            \
             H = fma(Pi * Pi, Hb, H);                                       \
             Pi *= Pb;                                                      \
@@ -806,7 +825,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);          // fixed part
             constexpr int NR = NB + QQ + 2 * PP + (FIT ? 1 : 0);
-            static_assert(NR + 5 <= XCH_SUMS, "exchange record too small");
+            static_assert(NR + 6 <= XCH_SUMS, "exchange record too small");
             double red[NR];
             red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
             if (!DENSE) red[5] = aSxx;
@@ -820,6 +839,12 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             S.X0 = readlane_d(Xs, 0);                  // :218  (wave 0)
             S.V0 = readlane_d(Vs, 0);                  // :219
             bool neg = __any(sneg < 0);                // log of a negative Sigma in the reference
+            int abort_now = 0;
+            if (!FIT && prm.abort && ((it + 1) & 63) == 0) {
+                // every wave of a multi-wave cell must see the SAME value (barrier counts):
+                // wave 0 polls, the flag travels with the sums record
+                if (wv == 0) abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
+            }
             if constexpr (W > 1) {
                 // partial sums of the W waves -> totals, formed by every wave in the same order
                 double *sx = xch + W * 12 + wv * XCH_SUMS;
@@ -828,6 +853,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                     for (int i = 0; i < NR; i++) sx[i] = red[i];
                     sx[NR] = termLast; sx[NR + 1] = term0; sx[NR + 2] = S.X0; sx[NR + 3] = S.V0;
                     sx[NR + 4] = neg ? 1.0 : 0.0;
+                    if (wv == 0) sx[NR + 5] = abort_now ? 1.0 : 0.0;
                 }
                 __syncthreads();
                 const double *s0 = xch + W * 12;
@@ -844,7 +870,9 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                 term0 = uniform_d(s0[NR + 1]);
                 S.X0 = uniform_d(s0[NR + 2]);
                 S.V0 = uniform_d(s0[NR + 3]);
+                abort_now = __builtin_amdgcn_readfirstlane((int)(s0[NR + 5] > 0.0));
             }
+            interrupted = abort_now != 0;
             S.Syx = red[0]; S.Tx1x = red[1];
             S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
@@ -873,7 +901,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         }
         if (prm.liks && lane == 0 && wv == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
-        bool stop = it >= prm.niter;
+        bool stop = it >= prm.niter || interrupted;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
 #ifdef LDSR_SC_PLAIN     // A/B switch: the round-1 form (vector loads through a plain pointer)
@@ -898,7 +926,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             prm.n_iter[cell] = it;
         }
         prm.lik[cell] = lik;
-        prm.status[cell] = isfinite(lik) ? 0 : 1;
+        prm.status[cell] = (interrupted && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
     }
 }
 

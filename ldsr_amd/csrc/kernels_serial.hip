@@ -256,6 +256,7 @@ __global__ __launch_bounds__(64) void em_serial_kernel(EmParams prm) {
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
+    bool interrupted = false;
     for (;;) {
         // ---------------- E-step, forward filter (src/EM.cpp:48-90) + likelihood (:113-124)
         double Xp = th.mu1, Vp = th.V1, Xu = 0.0, Vu = 0.0, acc = 0.0;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(64) void em_serial_kernel(EmParams prm) {
         // stop rule of src/EM.cpp:272 (needs three likelihoods), or iteration cap
         if (it >= prm.niter) break;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) break;
+        if (prm.abort && (it & 63) == 0 && ldsr_poll_abort(prm.abort)) { interrupted = true; break; }
 
         // ---------------- backward smoother (:94-104) fused with the M-step sums (:151-193)
         Sums<PP, QQ> S;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64) void em_serial_kernel(EmParams prm) {
         for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
     prm.lik[cell] = lik;
     prm.n_iter[cell] = it;
-    prm.status[cell] = isfinite(lik) ? 0 : 1;
+    prm.status[cell] = interrupted ? 3 : (isfinite(lik) ? 0 : 1);
 }
 
 // ---------------------------------------------------------------------------------------

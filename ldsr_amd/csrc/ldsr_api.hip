@@ -2,7 +2,10 @@
 // carving, block tables, launches, restart selection.  No numerics live here.
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +43,69 @@ extern "C" int ldsr_device_count(void) {
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- user interrupts ---------------------------------------------------------------------------
+// One host-pinned flag for the whole library: kernels launched while a callback is registered
+// poll it; only the thread that entered the library from outside (t_poll) runs the callback.
+static struct {
+    std::mutex mu;
+    int (*cb)(void *) = nullptr;
+    void *arg = nullptr;
+    int *flag = nullptr;              // pinned, portable
+    std::atomic<int> active{0};       // external EM calls in flight
+} g_intr;
+static thread_local bool t_poll = false;     // this thread may run the callback
+static thread_local bool t_worker = false;   // a library worker thread: never runs it
+
+extern "C" int ldsr_set_interrupt_callback(int (*callback)(void *), void *arg) {
+    std::lock_guard<std::mutex> lk(g_intr.mu);
+    if (callback && !g_intr.flag) {
+        void *p = nullptr;
+        HIPCHK(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
+        g_intr.flag = (int *)p;
+        *g_intr.flag = 0;
+    }
+    g_intr.cb = callback;
+    g_intr.arg = arg;
+    return LDSR_OK;
+}
+
+static const int *intr_flag_for_kernels() { return g_intr.cb ? g_intr.flag : nullptr; }
+static bool intr_raised() { return g_intr.cb && g_intr.flag && *(volatile int *)g_intr.flag != 0; }
+
+// Run the callback (external caller thread only); raise the flag if it asks to stop.
+static void intr_poll() {
+    if (!t_poll || !g_intr.cb || !g_intr.flag) return;
+    if (*(volatile int *)g_intr.flag == 0 && g_intr.cb(g_intr.arg)) *(volatile int *)g_intr.flag = 1;
+}
+
+// RAII around an external EM entry: the outermost call on a non-worker thread becomes the poller
+// and clears a stale flag when no other call is in flight.
+struct IntrScope {
+    bool owner = false;
+    IntrScope() {
+        if (t_worker || t_poll || !g_intr.cb) return;
+        owner = true;
+        t_poll = true;
+        if (g_intr.active.fetch_add(1) == 0 && g_intr.flag) *(volatile int *)g_intr.flag = 0;
+    }
+    ~IntrScope() {
+        if (!owner) return;
+        g_intr.active.fetch_sub(1);
+        t_poll = false;
+    }
+};
+
+// Wait for a stream; the polling thread keeps the interrupt callback alive meanwhile.
+static hipError_t wait_stream(hipStream_t stream) {
+    if (!t_poll) return hipStreamSynchronize(stream);
+    for (unsigned n = 0;; n++) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((n & 15) == 15) intr_poll();
+        usleep(50);
+    }
+}
 
 // ---- optional kernel timer: HIP events around the EM kernel, on its launch stream ------------
 // Slots are handed out under a mutex (ldsr_em_batch_multi / _groups call in from worker
@@ -243,6 +309,14 @@ extern "C" void ldsr_shutdown(void) {
             s = StageSlot();
         }
     }
+    {
+        std::lock_guard<std::mutex> lk(g_intr.mu);
+        if (g_intr.flag && g_intr.active.load() == 0) {
+            (void)hipHostFree(g_intr.flag);
+            g_intr.flag = nullptr;
+            g_intr.cb = nullptr;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_arena_mu);
     std::vector<Arena *> keep;
     for (Arena *a : g_arenas) {
@@ -394,7 +468,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 int shared_uv, const int *cell_offsets, const double *d_theta0,
                                 int niter, double tol, int algo, double *d_theta, double *d_lik,
                                 int *d_n_iter, int *d_status, double *d_liks, int liks_nanfill,
-                                void *d_workspace, size_t workspace_bytes) {
+                                void *d_workspace, size_t workspace_bytes,
+                                const int *abort_flag = nullptr) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -452,6 +527,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.T = T; prm.p = p; prm.q = q; prm.has_u = d_u != nullptr; prm.has_v = d_v != nullptr;
     prm.niter = niter; prm.n_cells = n_cells; prm.tol = tol;
     prm.liks_nanfill = liks_nanfill;
+    prm.abort = abort_flag;
     prm.yp = (const double *)(ws + L.yp);
     prm.yz = (const double *)(ws + L.yz);
     prm.up = (const double *)(ws + L.up);
@@ -715,7 +791,7 @@ static int slice_run(Slice &S) {
         S.shared_uv, S.off.data(), (const double *)(A->dev + S.d_th0), S.niter, S.tol, S.algo,
         (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
         (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
-        S.liks != nullptr, A->dev + S.d_ws, S.wsb);
+        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels());
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
     if (S.fuse && S.trace_on_device) {
@@ -761,7 +837,8 @@ static int slice_run(Slice &S) {
             HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
         HIPCHK(hipMemcpyAsync(pw + W.out_begin, dw + W.out_begin, W.out_bytes, hipMemcpyDeviceToHost,
                               A->stream));
-        HIPCHK(hipStreamSynchronize(A->stream));
+        HIPCHK(wait_stream(A->stream));
+        if (intr_raised()) return fail(LDSR_EINTERRUPTED, "interrupted by the caller's interrupt callback");
         if (S.want_all) {
             memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
             memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
@@ -787,7 +864,7 @@ static int slice_run(Slice &S) {
         return LDSR_OK;
     }
     HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
-    HIPCHK(hipStreamSynchronize(A->stream));
+    HIPCHK(wait_stream(A->stream));
     memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
     memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
     memcpy(S.n_iter, pout + (S.d_nit - S.d_out), sizeof(int) * (size_t)n);
@@ -921,15 +998,26 @@ static int run_slices(std::vector<Slice> &sl) {
     const size_t n = sl.size();
     std::vector<int> rcs(n, LDSR_OK);
     std::vector<std::string> msgs(n);
-    auto work = [&](size_t d) {
+    std::atomic<int> running{0};
+    auto work = [&](size_t d, bool worker) {
+        if (worker) t_worker = true;
         rcs[d] = slice_run(sl[d]);
         if (rcs[d]) msgs[d] = g_err;      // thread-local message of this worker
+        if (worker) running.fetch_sub(1);
     };
     std::vector<std::thread> pool;
     for (size_t d = 1; d < n; d++)
-        if (sl[d].n_series > 0) pool.emplace_back(work, d);
-    if (n > 0 && sl[0].n_series > 0) work(0);
+        if (sl[d].n_series > 0) {
+            running.fetch_add(1);
+            pool.emplace_back(work, d, true);
+        }
+    if (n > 0 && sl[0].n_series > 0) work(0, false);
+    while (t_poll && running.load() > 0) {     // keep the interrupt callback alive while joining
+        intr_poll();
+        usleep(200);
+    }
     for (auto &t : pool) t.join();
+    if (intr_raised()) return fail(LDSR_EINTERRUPTED, "interrupted by the caller's interrupt callback");
     for (size_t d = 0; d < n; d++)
         if (rcs[d]) return fail(rcs[d], "device " + std::to_string(sl[d].device) + ": " + msgs[d]);
     return LDSR_OK;
@@ -947,6 +1035,7 @@ extern "C" int ldsr_em_batch_multi(int n_devices, const int *devices, int n_seri
     if (rc) return rc;
     if (!theta0 || !theta || !lik || !n_iter || !status) return fail(LDSR_EINVAL, "NULL pointer");
     if (cell_offsets[n_series] == 0) return LDSR_OK;
+    IntrScope intr;
     std::vector<Slice> sl;
     std::vector<int> lo_of, s0_of;
     make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
@@ -980,6 +1069,7 @@ extern "C" int ldsr_em_restart_grid(int n_devices, const int *devices, int n_ser
     const int n_cells = cell_offsets[n_series];
     const int P = 6 + p + q;
     const double nan = std::numeric_limits<double>::quiet_NaN();
+    IntrScope intr;
     if (n_devices > n_cells) n_devices = n_cells > 0 ? n_cells : 1;
     // One slice: selection and the winners' fit are fused behind the EM kernel on the device and
     // the per-cell arrays cross PCIe only if asked for.  Several slices: per-cell results come
@@ -1079,6 +1169,8 @@ extern "C" int ldsr_em_restart_groups(int n_devices, const int *devices, int n_g
     if (n_devices < 1 || !devices) return fail(LDSR_EINVAL, "n_devices must be >= 1");
     if (n_groups < 0 || (n_groups > 0 && !groups)) return fail(LDSR_EINVAL, "groups must not be NULL");
     std::vector<std::string> msgs((size_t)n_groups);
+    IntrScope intr;
+    std::atomic<int> running{0};
     auto work = [&](int g) {
         ldsr_group &G = groups[g];
         // rotate the device list so that concurrent groups start on different GPUs
@@ -1093,11 +1185,20 @@ extern "C" int ldsr_em_restart_groups(int n_devices, const int *devices, int n_g
     // a bounded pool: at most 8 groups in flight (each holds one arena per device)
     const int n_workers = std::min(n_groups, 8);
     std::vector<std::thread> pool;
-    for (int w = 0; w < n_workers; w++)
+    for (int w = 0; w < n_workers; w++) {
+        running.fetch_add(1);
         pool.emplace_back([&, w]() {
+            t_worker = true;
             for (int g = w; g < n_groups; g += n_workers) work(g);
+            running.fetch_sub(1);
         });
+    }
+    while (t_poll && running.load() > 0) {     // the caller's thread keeps the interrupt callback alive
+        intr_poll();
+        usleep(200);
+    }
     for (auto &t : pool) t.join();
+    if (intr_raised()) return fail(LDSR_EINTERRUPTED, "interrupted by the caller's interrupt callback");
     for (int g = 0; g < n_groups; g++)
         if (groups[g].rc) return fail(groups[g].rc, "group " + std::to_string(g) + ": " + msgs[(size_t)g]);
     return LDSR_OK;

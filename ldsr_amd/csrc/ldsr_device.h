@@ -181,6 +181,7 @@ struct EmParams {
     const double *theta0;    // [n_cells][6+p+q]
     double *theta, *lik, *liks;
     int *n_iter, *status;
+    const int *abort;        // host-pinned interrupt flag polled every 64 EM iterations, or null
     double *scratch;         // serial kernel: [T][2][scratch_stride]
     long scratch_stride;
     // FIT variant of the scan kernel (one E-step at theta0, the full fit written out)
@@ -189,5 +190,11 @@ struct EmParams {
     double lambda;
     int stdlik;              // divide lik by n_obs (src/EM.cpp:124)
 };
+
+// One system-scope load of the interrupt flag (pinned host memory written by the waiting host
+// thread): bypasses the GPU caches, costs one PCIe round trip -- hence only every 64 iterations.
+__device__ __forceinline__ int ldsr_poll_abort(const int *flag) {
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #define LDSR_LOG_2PI 1.8378770664093454835606594728112

@@ -104,6 +104,33 @@ def cv_metrics(Ycv, target, Z, robust_mean=True):
     return cols, mean
 
 
+def cv_grid_ensemble(y, members, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed=1,
+                     mu=0.0, devices=(0,)):
+    """cvLDS with lists of u, v (R/LDS_reconstruction.R:377-381): every fold is fitted with
+    every ensemble member (members may differ in p and q) and the members' cross-validated
+    series are averaged (`.final = rowMeans`).  All members x folds x restarts run inside ONE
+    library call.  Returns dict(Ycv [n_folds, len(inst_period)] = member mean + mu, members =
+    the per-member results)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    inst_period = np.asarray(inst_period)
+    F = len(Z)
+    Y = np.repeat(y[None], F, axis=0)
+    for f, z in enumerate(Z):
+        Y[f, inst_period[np.asarray(z)]] = np.nan          # y[instPeriod][z] <- NA  (:274)
+    inits = []
+    for g, (u, v) in enumerate(members):
+        p = 1 if u is None else np.asarray(u).shape[0]
+        q = 1 if v is None else np.asarray(v).shape[0]
+        inits.append(make_init_packed(p, q, F * num_restarts, seed=seed + 1000 * g))
+    res = api.ensemble_restart(Y, members, inits, niter=niter, tol=tol, devices=devices)
+    for g, r in enumerate(res):
+        if np.any(r["winner"] < 0):
+            raise RuntimeError("member %d, fold %d: no restart produced a finite likelihood"
+                               % (g, int(np.nonzero(r["winner"] < 0)[0][0])))
+    Ycv = np.mean([r["Y"][:, inst_period] for r in res], axis=0) + mu
+    return {"Ycv": Ycv, "members": res, "Z": Z}
+
+
 def cv_grid(y, u, v, inst_period, Z, num_restarts=20, niter=1000, tol=1e-5, seed=1, r_seed=None,
             mu=0.0, device=0, devices=None, engine=None):
     """All folds x restarts in one launch.

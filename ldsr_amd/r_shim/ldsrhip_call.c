@@ -137,6 +137,13 @@ static SEXP model_to_list(const inputs_t *in, const double *theta, const double 
     return out;
 }
 
+/* User interrupts while the GPU works: the library calls this about once per millisecond from the
+ * .Call's own thread; R_CheckUserInterrupt would longjmp, so it runs inside R_ToplevelExec, which
+ * reports a pending interrupt as FALSE instead (the reference polls every 100 EM iterations,
+ * src/EM.cpp:261-262). */
+static void check_interrupt(void *unused) { (void)unused; R_CheckUserInterrupt(); }
+static int poll_interrupt(void *unused) { (void)unused; return R_ToplevelExec(check_interrupt, NULL) == FALSE; }
+
 static int *all_devices(int n_cells, int *n_dev) {
     int n = ldsr_device_count(); /* restarts shard over every GPU of the node, no collective */
     if (n < 1) Rf_error("ldsrhip: no ROCm device visible");
@@ -177,12 +184,14 @@ static SEXP em_restart(const double *Y, int F, const inputs_t *in, SEXP *inits, 
     double *liks_w = (double *)R_alloc((size_t)F * niter, sizeof(double));
     double *X = (double *)R_alloc((size_t)4 * F * T, sizeof(double));
     double *Yf = X + (size_t)F * T, *V = Yf + (size_t)F * T, *J = V + (size_t)F * T;
-    R_CheckUserInterrupt(); /* the reference polls every 100 iterations (src/EM.cpp:261-262) */
+    R_CheckUserInterrupt();
     int n_dev;
     int *devs = all_devices(n, &n_dev);
+    (void)ldsr_set_interrupt_callback(poll_interrupt, NULL); /* polled during the run, see above */
     const int rc = ldsr_em_restart_grid(n_dev, devs, F, T, p, q, Y, in->u, in->v, 1, off, th0, niter,
                                         tol, LDSR_ALGO_AUTO, theta_all, lik_all, nit_all, st_all,
                                         winner, theta_w, lik_w, nit_w, liks_w, X, Yf, V, J);
+    if (rc == LDSR_EINTERRUPTED) Rf_error("ldsrhip: interrupted by the user");
     if (rc != LDSR_OK) Rf_error("ldsr_em_restart_grid: %s", ldsr_last_error());
     for (int c = 0; c < n; c++)
         if (st_all[c] == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular"); /* arma::inv throws */
@@ -257,8 +266,10 @@ SEXP ldsrhip_LDS_EM(SEXP y, SEXP u, SEXP v, SEXP theta0, SEXP niterS, SEXP tolS)
     double *X = liks + niter, *Y = X + T, *V = Y + T, *J = V + T, lik, flik;
     int n_iter, status;
     R_CheckUserInterrupt();
+    (void)ldsr_set_interrupt_callback(poll_interrupt, NULL);
     int rc = ldsr_em_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th0, niter, Rf_asReal(tolS),
                            LDSR_ALGO_AUTO, th, &lik, &n_iter, &status, liks);
+    if (rc == LDSR_EINTERRUPTED) Rf_error("ldsrhip: interrupted by the user");
     if (rc != LDSR_OK) Rf_error("ldsr_em_batch: %s", ldsr_last_error());
     if (status == LDSR_CELL_SINGULAR) Rf_error("inv(): matrix is singular");
     rc = ldsr_smooth_batch(0, 1, T, in.p, in.q, REAL(y), in.u, in.v, 0, off, th, 1, X, Y, V, J, &flik);

@@ -43,4 +43,5 @@ void Rf_unprotect(int);
 void Rf_error(const char *, ...);
 char *R_alloc(size_t, int);
 void R_CheckUserInterrupt(void);
+int R_ToplevelExec(void (*fun)(void *), void *data);   /* Rboolean in R: FALSE if fun was interrupted */
 #endif

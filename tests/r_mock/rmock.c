@@ -35,6 +35,7 @@ static size_t g_nobj = 0, g_cap = 0;
 static int g_protect = 0, g_interrupt_polls = 0;
 static jmp_buf g_jmp;
 static int g_jmp_armed = 0;
+void Rf_error(const char *fmt, ...);
 static char g_errmsg[512];
 static const R_CallMethodDef *g_table = NULL;
 
@@ -114,7 +115,29 @@ SEXP Rf_ScalarInteger(int x) { SEXP s = Rf_allocVector(INTSXP, 1); INTEGER(s)[0]
 SEXP Rf_protect(SEXP s) { g_protect++; return s; }
 void Rf_unprotect(int n) { g_protect -= n; }
 char *R_alloc(size_t n, int size) { return (char *)track(calloc(n ? n : 1, (size_t)size)); }
-void R_CheckUserInterrupt(void) { g_interrupt_polls++; }
+/* Scripted user interrupt: the (n+1)-th poll from now behaves like a pending Ctrl-C -- inside
+ * R_ToplevelExec it unwinds to it (which then returns FALSE), elsewhere it is an R error. */
+static jmp_buf g_tl_jmp;
+static int g_tl_armed = 0, g_intr_after = -1;
+void rmock_interrupt_after(int n_polls) { g_intr_after = n_polls < 0 ? -1 : g_interrupt_polls + n_polls; }
+void R_CheckUserInterrupt(void) {
+    g_interrupt_polls++;
+    if (g_intr_after >= 0 && g_interrupt_polls > g_intr_after) {
+        g_intr_after = -1;
+        if (g_tl_armed) longjmp(g_tl_jmp, 1);
+        Rf_error("interrupt");
+    }
+}
+int R_ToplevelExec(void (*fun)(void *), void *data) {
+    g_tl_armed = 1;
+    if (setjmp(g_tl_jmp)) {
+        g_tl_armed = 0;
+        return 0;
+    }
+    fun(data);
+    g_tl_armed = 0;
+    return 1;
+}
 
 void Rf_error(const char *fmt, ...) {
     va_list ap;

@@ -138,6 +138,23 @@ def test_heterogeneous_ensemble_groups(eng, p1case):
         assert np.array_equal(r["all"]["theta"], solo["all"]["theta"])
 
 
+def test_cv_ensemble_folds_times_members(eng, npcase):
+    """cvLDS with lists of u, v (R/LDS_reconstruction.R:377-381; tests/testthat/test-ensemble.R:9-18,
+    non-contiguous folds): folds x members in one call == the mean of per-member cv_grid runs."""
+    from ldsr_amd import cv
+    c = npcase(1800)
+    inst = np.nonzero(~np.isnan(c["y"]))[0]
+    Z = [np.array([1, 5, 9, 13, 40]), np.arange(20, 27), np.array([0, 2, 44, 45])]
+    members = [(c["u"][:3], c["v"][:2]), (c["u"][:2], c["v"][:3])]         # 3 and 2 rows, as the reference's test
+    r = cv.cv_grid_ensemble(c["y"], members, inst, Z, num_restarts=6, niter=60, tol=1e-5, seed=3, mu=c["mu"])
+    assert r["Ycv"].shape == (3, inst.size) and np.all(np.isfinite(r["Ycv"]))
+    solo = [cv.cv_grid(c["y"], u, v, inst, Z, num_restarts=6, niter=60, tol=1e-5, seed=3 + 1000 * g)
+            for g, (u, v) in enumerate(members)]
+    assert np.allclose(r["Ycv"], np.mean([s["Ycv"] for s in solo], axis=0) + c["mu"], rtol=0, atol=1e-12)
+    for g in range(2):
+        assert np.array_equal(r["members"][g]["theta"], solo[g]["theta"])
+
+
 def _device_call(L, stream_ptr, S, T, p, q, d, off_c, niter, tol, ws_ptr, wsb):
     from ldsr_amd import _lib
     _lib.check(L.ldsr_em_batch_device(
@@ -216,3 +233,31 @@ def test_queue_is_reset_between_launches_sharing_a_workspace(eng):
         ref = eng.em_batch(Y, u, v, t0, cell_offsets=offs, niter=40, tol=1e-5)
         assert np.array_equal(o["nit"].cpu().numpy(), ref["n_iter"])      # no cell skipped (-1) or redone
         assert np.array_equal(o["th"].cpu().numpy(), ref["theta"])
+
+
+def test_interrupt_callback_stops_cells_and_reports_it(eng):
+    """C ABI level: a registered callback is polled by the calling thread while the device
+    works; once it returns non-zero every cell stops at a multiple of 64 iterations with status
+    LDSR_CELL_INTERRUPTED and the call returns LDSR_EINTERRUPTED.  Unregistered: no polling."""
+    from ldsr_amd import _lib, synth
+    L = _lib.lib()
+    y, u, v = synth.make_series(1000, 1, 2, series_id=6)
+    th0 = synth.make_init_packed(1, 2, 1024, seed=2)
+    calls = {"n": 0}
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p)
+    def cb(_):
+        calls["n"] += 1
+        return 1 if calls["n"] >= 5 else 0
+
+    assert L.ldsr_set_interrupt_callback(C.cast(cb, C.c_void_p), None) == 0
+    try:
+        for devices in (None, [0, 0]):              # the caller's thread polls in both forms
+            calls["n"] = 0
+            with pytest.raises(_lib.LdsrError, match="error 4"):
+                eng.em_batch(y, u, v, th0, niter=40000, tol=0.0, devices=devices)
+            assert calls["n"] >= 5
+    finally:
+        assert L.ldsr_set_interrupt_callback(None, None) == 0
+    r = eng.em_batch(y, u, v, th0[:64], niter=130, tol=0.0)       # no callback: runs to the cap
+    assert np.all(r["n_iter"] == 130) and np.all(r["status"] == 0)

@@ -25,6 +25,7 @@ class RMock:
                 ("rmock_routine_name", C.c_char_p, [ip]), ("rmock_routine_nargs", ip, [ip]),
                 ("rmock_last_error", C.c_char_p, []), ("rmock_protect_depth", ip, []),
                 ("rmock_interrupt_polls", ip, []), ("rmock_reset", None, []),
+                ("rmock_interrupt_after", None, [ip]),
                 ("rmock_call", ip, [C.c_char_p, ip, C.POINTER(vp), C.POINTER(vp)]),
                 ("rmock_real_matrix", vp, [ip, ip, C.POINTER(C.c_double)]),
                 ("rmock_scalar", vp, [ip, C.c_double]), ("rmock_list", vp, [ip, ip]),
@@ -240,3 +241,27 @@ def test_grid_entry_equals_the_python_binding(R, npcase):
         assert m["fit"]["Y"].shape == (1, T) and np.array_equal(m["fit"]["Y"][0], ref["Y"][f])
         assert m["lik"][0] == ref["lik"][f]
         assert m["theta"]["C"][0, 0] == ref["theta"][f, 4]
+
+
+@pytest.mark.gpu
+def test_user_interrupt_stops_a_running_launch(R, p1case):
+    """The reference polls Rcpp::checkUserInterrupt() every 100 iterations (src/EM.cpp:261-262).
+    Here the .Call thread polls R_CheckUserInterrupt (inside R_ToplevelExec) about once per
+    millisecond while the GPU works; a pending interrupt stops every cell within 64 iterations and
+    the routine raises an R error with the PROTECT stack unwound."""
+    import time
+    from ldsr_amd import synth
+    y, u, v = synth.make_series(1000, 1, 2, series_id=5)
+    th0 = synth.make_init_packed(1, 2, 2048, seed=8)
+    init = [_theta_list(t, 1, 2) for t in th0]
+    args = (y[None, :], u, v, init, 40000, 0.0)               # ~0.3 s of EM if left alone
+    R.call("ldsrhip_LDS_EM_batch", y[None, :], u, v, init[:8], 5, 0.0)     # warm up (allocations)
+    R.L.rmock_interrupt_after(10)                              # the 10th poll from now is a Ctrl-C
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="interrupted by the user"):
+        R.call("ldsrhip_LDS_EM_batch", *args)
+    dt = time.perf_counter() - t0
+    assert dt < 0.15, "the launch was not cut short: %.3f s" % dt
+    assert R.L.rmock_protect_depth() == 0
+    m = R.call("ldsrhip_LDS_EM_batch", y[None, :], u, v, init[:8], 5, 0.0)   # the next call is unaffected
+    assert m["liks"].shape == (5, 1)
