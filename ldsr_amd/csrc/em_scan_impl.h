@@ -149,6 +149,14 @@ __device__ __forceinline__ double dppz(double src) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// ... and with 1.0 as the out-of-range value: its low word is 0 (hardware-supplied), only the
+// high word 0x3FF00000 needs an `old` register.
+template <int CTRL>
+__device__ __forceinline__ double dpp1(double src) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(src), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 #define DPP_ROW_SHL(n) (0x100 + (n))
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_WAVE_SHL1 0x130
@@ -160,15 +168,18 @@ __device__ __forceinline__ double dppz(double src) {
 template <int CTRL, int RM>
 __device__ __forceinline__ PMat pdpp(const PMat &m) {
     PMat r;
-    r.m00 = dppd<CTRL, RM>(1.0, m.m00);
-    r.m11 = dppd<CTRL, RM>(1.0, m.m11);
-    r.m22 = dppd<CTRL, RM>(1.0, m.m22);
-    if constexpr (RM == 0xF && LDSR_DPP_BOUND_CTRL) {     // zero entries: hardware-supplied 0
+    if constexpr (RM == 0xF && LDSR_DPP_BOUND_CTRL) {     // zero entries / words: hardware-supplied 0
+        r.m00 = dpp1<CTRL>(m.m00);
+        r.m11 = dpp1<CTRL>(m.m11);
+        r.m22 = dpp1<CTRL>(m.m22);
         r.m01 = dppz<CTRL>(m.m01);
         r.m10 = dppz<CTRL>(m.m10);
         r.m20 = dppz<CTRL>(m.m20);
         r.m21 = dppz<CTRL>(m.m21);
     } else {
+        r.m00 = dppd<CTRL, RM>(1.0, m.m00);
+        r.m11 = dppd<CTRL, RM>(1.0, m.m11);
+        r.m22 = dppd<CTRL, RM>(1.0, m.m22);
         r.m01 = dppd<CTRL, RM>(0.0, m.m01);
         r.m10 = dppd<CTRL, RM>(0.0, m.m10);
         r.m20 = dppd<CTRL, RM>(0.0, m.m20);
@@ -651,7 +662,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         // Within rows by DPP row shifts (identity outside the row) ...
 #define RSCAN_ROUND(n)                                                     \
         {                                                                  \
-            const double Pb = dppd<DPP_ROW_SHL(n), 0xF>(1.0, Pi);          \
+            const double Pb = LDSR_DPP_BOUND_CTRL ? dpp1<DPP_ROW_SHL(n)>(Pi) : dppd<DPP_ROW_SHL(n), 0xF>(1.0, Pi); \
             const double Gb = LDSR_DPP_BOUND_CTRL ? dppz<DPP_ROW_SHL(n)>(G) : dppd<DPP_ROW_SHL(n), 0xF>(0.0, G); \
             const double Hb = LDSR_DPP_BOUND_CTRL ? dppz<DPP_ROW_SHL(n)>(H) : dppd<DPP_ROW_SHL(n), 0xF>(0.0, H); \
             G = fma(Pi, Gb, G);                                            \
