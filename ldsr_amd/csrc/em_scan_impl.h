@@ -223,6 +223,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_WIDE_SB      // scheduling barrier after every step of the wide kernels' sweeps
 #define LDSR_WIDE_SB 0
 #endif
+#ifndef LDSR_EB_ALIAS        // F1 hands e_t, B u_t to F2 through the (not yet live) g_t / h_t slots
+#define LDSR_EB_ALIAS 1
+#endif
 #ifndef LDSR_DENSE_F1_POW    // dense series: chunk composite = power of the 2x2 block + row recursion
 #define LDSR_DENSE_F1_POW 1
 #endif
@@ -399,6 +402,13 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     constexpr int NS = L - HS;
     double Jv[NS], gv_[NS], hv[NS];
     double ev[EBR ? L : 1], buv[EBR ? L : 1];
+    // Short chunks (everything stored): F1 leaves e_t = y_t - D v_t and B u_t in the slots of
+    // g_t / h_t, which are not live before F2 reaches step t -- F2 neither re-reads the series
+    // from LDS nor re-forms the q + p products.  No extra registers on paper, but the masked
+    // (!DENSE) kernels at L = 14..16 sit at the 256-VGPR limit and the longer live ranges cost
+    // them spills: same-box A/B +4 % (cfg2), +8.5 % (cfg3, cfg5 at L = 13) where enabled, -1..-10 %
+    // on masked series at L = 15, 16 -- hence the condition.
+    constexpr bool EBA = (L <= 16) && (DENSE || L <= 13) && !EBR && LDSR_EB_ALIAS;
     double Jfin = 0.0;      // FIT: J[T-1] of src/EM.cpp:98 (the backward recursion itself uses 0)
 
     for (;;) {
@@ -428,6 +438,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             const bool o = DENSE || ((obsmask >> j) & 1u);
             const double e = e_at(j), bu = bu_at(j);
             if constexpr (EBR) { ev[j] = e; buv[j] = bu; }
+            if (EBA && j < L - 1) { gv_[j] = e; hv[j] = bu; }   // (the predicated L-th step re-reads)
             const double a00 = o ? alpha : A2;
             const double g = o ? C2R : 0.0;
             const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
@@ -480,6 +491,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
                 for (int j = L - 2; j >= 0; j--) {
                     const double e = e_at(j), bu = bu_at(j);
+                    if constexpr (EBA) { gv_[j] = e; hv[j] = bu; }
                     const double s20 = fma(bu, C2R, ACR * e);
                     const double na = fma(ra, alpha, fma(rb, C2R, rc * s20));
                     rb = fma(ra, Q, fma(rc, bu, rb));
@@ -583,6 +595,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             if constexpr (PF) {
                 e = e_nx; bu = bu_nx;
                 if (j + 1 < L) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
+            } else if (EBA && j < L - 1) {
+                e = gv_[j]; bu = hv[j];                // left there by F1; overwritten below by g_t, h_t
             } else {
                 e = EBR ? ev[j] : e_at(j);
                 bu = EBR ? buv[j] : bu_at(j);
