@@ -407,7 +407,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     // from LDS nor re-forms the q + p products.  No extra registers on paper, but the masked
     // (!DENSE) kernels at L = 14..16 sit at the 256-VGPR limit and the longer live ranges cost
     // them spills: same-box A/B +4 % (cfg2), +8.5 % (cfg3, cfg5 at L = 13) where enabled, -1..-10 %
-    // on masked series at L = 15, 16 -- hence the condition.
+    // on masked series at L = 15, 16 (scheduling barriers in F1 do not help: 63 spilled VGPRs
+    // either way) -- hence the condition.
     constexpr bool EBA = (L <= 16) && (DENSE || L <= 13) && !EBR && LDSR_EB_ALIAS;
     double Jfin = 0.0;      // FIT: J[T-1] of src/EM.cpp:98 (the backward recursion itself uses 0)
 

@@ -35,3 +35,41 @@ def test_cpu_baseline_leg_runs():
     r = bench.cpu_baseline(1, 2, 2, Y, U, V, seed=1)
     assert r["kind"] == "port" and r["value"] > 0 and r["cores"] >= 1
     assert bench.bytes_per_unit(1000, 1, 2) == 96000
+
+
+def test_pmc_summary_is_only_used_for_the_kernel_it_was_measured_on():
+    """roofline.traffic / issue_frac come from committed rocprofv3 passes: an entry counts only
+    for the workload AND kernel instantiation AND iteration setup it was measured on; anything
+    else is flagged stale (round 1 printed constants of an older kernel unconditionally)."""
+    import json
+    import bench
+    entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["entries"]
+    e = [x for x in entries if x["workload"] == "cfg2"][0]
+    got, stale = bench.load_pmc("cfg2", "dense", e["kernel"], e["niter"], e["tol"])
+    assert got is e or got == e
+    assert stale is False
+    got, stale = bench.load_pmc("cfg2", "dense", "em_scan_kernel<9, 9, 99, 1, false, false, false>", 100, 0.0)
+    assert stale is True and got["workload"] == "cfg2"
+    got, stale = bench.load_pmc("cfg2", "dense", e["kernel"], 1000, 1e-5)
+    assert stale is True
+    assert bench.load_pmc("custom", "dense", e["kernel"], 100, 0.0) == (None, None)
+    assert bench.flops_per_unit(1000, 1, 2) == 68000           # SURVEY.md 8(a)
+
+
+def test_plain_multi_gpu_invocation_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE starts N ranks as a child
+    torch.distributed.run (no exec from a GPU-initialised process) on 127.0.0.1."""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    assert bench.spawn_ranks(8) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
