@@ -226,6 +226,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_EB_ALIAS        // F1 hands e_t, B u_t to F2 through the (not yet live) g_t / h_t slots
 #define LDSR_EB_ALIAS 1
 #endif
+#ifndef LDSR_F2_BARRIER_EVERY   // scheduling barrier every n steps of F2 where the hand-over is on (0 = none)
+#define LDSR_F2_BARRIER_EVERY 8
+#endif
 #ifndef LDSR_DENSE_F1_POW    // dense series: chunk composite = power of the 2x2 block + row recursion
 #define LDSR_DENSE_F1_POW 1
 #endif
@@ -404,12 +407,13 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
     double ev[EBR ? L : 1], buv[EBR ? L : 1];
     // Short chunks (everything stored): F1 leaves e_t = y_t - D v_t and B u_t in the slots of
     // g_t / h_t, which are not live before F2 reaches step t -- F2 neither re-reads the series
-    // from LDS nor re-forms the q + p products.  No extra registers on paper, but the masked
-    // (!DENSE) kernels at L = 14..16 sit at the 256-VGPR limit and the longer live ranges cost
-    // them spills: same-box A/B +4 % (cfg2), +8.5 % (cfg3, cfg5 at L = 13) where enabled, -1..-10 %
-    // on masked series at L = 15, 16 (scheduling barriers in F1 do not help: 63 spilled VGPRs
-    // either way) -- hence the condition.
-    constexpr bool EBA = (L <= 16) && (DENSE || L <= 13) && !EBR && LDSR_EB_ALIAS;
+    // from LDS nor re-forms the q + p products.  No extra registers on paper; in practice the
+    // scheduler postponed the J / g / h arithmetic of many steps to shorten the recurrence's
+    // critical path, which kept (Xu, Vu, Xp1, z, Sigma) of all those steps alive and spilled 24-73
+    // VGPRs -- a scheduling barrier every 8 steps of F2 (LDSR_F2_BARRIER_EVERY) bounds that: no
+    // spills on the narrow kernels, 21-23 on (4,8).  Same-box A/B of hand-over + barrier: cfg2
+    // 1.537 -> 1.41 ms, cfg3 6.08 -> 5.24, cfg5 9.18 -> 8.47, masked (1,2) 1.71 -> 1.61.
+    constexpr bool EBA = (L <= 16) && !EBR && LDSR_EB_ALIAS;
     double Jfin = 0.0;      // FIT: J[T-1] of src/EM.cpp:98 (the backward recursion itself uses 0)
 
     for (;;) {
@@ -646,6 +650,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             Xp = Xp1;
             Vp = Vp1;
             if (L > 16 || SB) __builtin_amdgcn_sched_barrier(0);
+            if (EBA && LDSR_F2_BARRIER_EVERY > 0 && (j % LDSR_F2_BARRIER_EVERY) == LDSR_F2_BARRIER_EVERY - 1)
+                __builtin_amdgcn_sched_barrier(0);
         };
         if (act) {
 #pragma unroll

@@ -1,10 +1,9 @@
 """Register budget of the scan kernels that run BASELINE's T=1000 configs (compile-time check,
 no GPU).  A refactor of the LDS accessors once cost the config-2 kernel 70 spilled VGPRs without
-any test noticing, so the budget is pinned: two waves per SIMD everywhere; the narrow kernels
-carry the <= 30 VGPRs (<= 128 B of scratch per lane, touched once per EM iteration, outside the
-per-step loops) that handing e_t / B u_t from F1 to F2 through the g/h slots costs their dense
-path -- accepted on a same-box A/B (+4 % at config 2); the wide config-3
-kernel must not spill more than it does today.  Parses hipcc's
+any test noticing, and the F1 -> F2 hand-over of e_t / B u_t spilled 24-73 VGPRs until F2 got a
+scheduling barrier every 8 steps, so the budget is pinned: two waves per SIMD everywhere, no
+scratch on the narrow kernels, and the wide config-3 kernel must not spill more than it does
+today (23 VGPRs, 64 B).  Parses hipcc's
 -Rpass-analysis=kernel-resource-usage through tools/resource_usage.py (~1 min)."""
 import os
 import sys
@@ -27,9 +26,9 @@ def test_scan_kernel_register_budget():
                  "<1, 4, 16, 1, false, false, false>", "<1, 1, 16, 1, false, false, false>",
                  "<2, 2, 16, 1, false, false, false>"):
         vgpr, vspill, scratch, occ = get(tmpl)
-        assert occ == 2 and vspill <= 30 and scratch <= 128 and vgpr <= 256, (tmpl, vgpr, vspill, scratch, occ)
+        assert (vspill, scratch, occ) == (0, 0, 2) and vgpr <= 256, (tmpl, vgpr, vspill, scratch, occ)
     vgpr, vspill, scratch, occ = get("<4, 8, 16, 1, false, false, false>")      # config 3
-    assert occ == 2 and scratch <= 176, (vgpr, vspill, scratch, occ)
+    assert occ == 2 and scratch <= 64, (vgpr, vspill, scratch, occ)
     for tmpl in ("<1, 2, 16, 1, false, false, true>", "<4, 8, 16, 1, false, false, true>"):   # FIT forms
         vgpr, vspill, scratch, occ = get(tmpl)
         assert (vspill, scratch, occ) == (0, 0, 2), (tmpl, vgpr, vspill, scratch, occ)
