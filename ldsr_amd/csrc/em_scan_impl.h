@@ -232,6 +232,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_DENSE_F1_POW    // dense series: chunk composite = power of the 2x2 block + row recursion
 #define LDSR_DENSE_F1_POW 1
 #endif
+#ifndef LDSR_GIMG_PREFETCH   // the same pipeline for the global image (same-box A/B: 2-5 % slower -- off)
+#define LDSR_GIMG_PREFETCH 0
+#endif
 #ifndef LDSR_SCAN_PREFETCH   // one-step software pipeline of the LDS reads in the long-chunk sweeps
 #define LDSR_SCAN_PREFETCH 0  // (same-box A/B on cfg4: 10.72 ms with, 10.40 ms without -- off)
 #endif
@@ -591,7 +594,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         // Long chunks end every step with a scheduling barrier (register pressure), which would
         // also pin each step's LDS reads right before their use: software-pipeline them one step
         // ahead instead (PF) -- the reads of step j+1 are issued at the top of step j.
-        constexpr bool PF = L > 16 && !EBR && LDSR_SCAN_PREFETCH;
+        constexpr bool PF = L > 16 && !EBR && (LDSR_SCAN_PREFETCH || (GIMG && LDSR_GIMG_PREFETCH));
         double e_nx = 0.0, bu_nx = 0.0;
         if (PF && act) { e_nx = e_at(0); bu_nx = bu_at(0); }
         auto f2 = [&](int j) {
