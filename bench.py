@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["custom"])
     ap.add_argument("--shape", default=None, help="custom workload: T,p,q,restarts (one series, weak scaling)")
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 serial, 2 scan (1-4 waves per cell), 3 pair (two cells per wave)")
     ap.add_argument("--mask", default="dense", choices=["dense", "paleo"])
     ap.add_argument("--niter", type=int, default=None, help="EM iteration cap (default: the workload's 100)")
     ap.add_argument("--tol", type=float, default=0.0,

@@ -27,7 +27,7 @@ from .synth import make_init_packed
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
-ALGO_AUTO, ALGO_SERIAL, ALGO_SCAN = 0, 1, 2
+ALGO_AUTO, ALGO_SERIAL, ALGO_SCAN, ALGO_PAIR = 0, 1, 2, 3
 
 
 def _d(a):

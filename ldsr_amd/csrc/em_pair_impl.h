@@ -1,0 +1,480 @@
+// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of up to
+// 1024 steps with narrow inputs (T <= 32 L, L <= 32, padded p <= 2, q <= 4).
+//
+// Why.  In em_scan_kernel (one cell per 64-lane wave, em_scan_impl.h) half of the ~1500 VALU
+// instructions of an EM iteration at T = 1000 do not depend on the chunk length: the two
+// cross-lane scans, the all-reduce of the M-step sums, the closed-form M-step, the stop rule
+// and the log of the likelihood's determinant product are executed once per wave whatever the
+// wave holds.  Here a wave holds TWO cells of the same series, one per 32-lane half, each lane
+// owning up to 32 consecutive time steps: the per-step work per cell is unchanged (twice the
+// steps on half the lanes) while every per-wave item above is shared by two cells and both
+// scans and the reduction lose one round.
+//
+// What makes it fit.  Three per-step values (J_t, g_t, h_t: em_scan_impl.h) must survive from
+// the forward to the backward sweep; at L = 32 that is 96 doubles per lane -- 192 VGPRs, too
+// many for two waves per SIMD.  J_t and g_t stay in registers; h_t (needed only by the variance
+// recursion) goes through a per-wave LDS strip [step][lane] (one ds_write_b64 and two
+// ds_read_b64 per step, conflict-free), which with the 32-lane series image fills the CU's 160 KiB
+// exactly at eight waves.  Nothing but theta / lik / n_iter / status ever goes to HBM.
+//
+// Everything else -- projective step matrices, F1 / scan / F2, B1 / reverse scan / B2, the folded
+// log-determinant, the fused reduction, mstep_update() -- is em_scan_impl.h's algorithm (same
+// reference citations, /root/reference/src/EM.cpp:22-229,245-280), re-mapped to 32-lane halves:
+// rows 0,1 of the wave are cell `a`, rows 2,3 are cell `b`; theta is per half (VGPRs).
+// Cells are dealt statically (tol == 0) or pulled by each half from the per-series work queue
+// (tol > 0: a half whose cell has converged takes the next one while the other half goes on).
+#pragma once
+#include "em_scan_impl.h"
+
+__host__ __device__ constexpr long pair_image_doubles(int L, int PP, int QQ) {
+    return (long)32 * L * 2 * scan_pairs(PP, QQ);
+}
+// LDS strip of one wave: h_t of steps 0 .. L-2 for 64 lanes (the predicated step L-1 keeps its
+// h in a register)
+__host__ __device__ constexpr long pair_strip_doubles(int L) { return (long)64 * (L - 1); }
+
+__device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
+
+template <int PP, int QQ, int L, bool DENSE, bool QUEUE>
+__device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
+                                             int s, int c0, int nc, int lane, int wave) {
+    constexpr int KP = scan_pairs(PP, QQ);
+    const int half = lane >> 5, vl = lane & 31, hbase = lane & 32;
+    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * 32 + vl) * 2 + (i & 1)]; };
+    auto Yat = [&](int j) { return val(j, 0); };
+    auto Uat = [&](int j, int k) { return val(j, 1 + k); };
+    auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
+    const int T = prm.T;
+    const int P = 6 + prm.p + prm.q;
+    const SeriesConst *__restrict__ sc = prm.sc + s;
+    const int n_obs = sc->n_obs;
+    const int nl = (T + L - 1) / L;          // active lanes of a half
+    const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
+    const bool act = vl < nl;
+    const bool tail = vl < rp;
+    const int lastLane = nl - 1;             // (within the half) owner of step T-1
+    const int t0 = vl * (L - 1) + min(vl, rp);
+
+    unsigned obsmask = 0;
+    if (!DENSE && act) {
+        const double *gy = prm.yp + (long)s * T;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const double yv = (j < L - 1 || tail) ? gy[t0 + j] : NAN;
+            if (isfinite(yv)) obsmask |= (1u << j);
+        }
+    }
+
+    // this half's cell
+    int k = QUEUE ? 0 : 2 * wave + half;
+    if constexpr (QUEUE) {
+        if (vl == 0) k = atomicAdd(prm.queue + s, 1);
+        k = __shfl(k, hbase, 64);
+    }
+    bool alive = k < nc;
+    int cell = c0 + (alive ? k : 0);
+    Theta<PP, QQ> th;
+    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+
+    double lik = NAN, lik1 = NAN, lik2 = NAN;
+    int it = 0;
+    double Jv[L], gv_[L];
+    double hlast = 0.0;      // h of the predicated step L-1
+    int wit = 0;             // wave-uniform iteration count (interrupt poll)
+
+    while (__any(alive)) {
+        const double A = th.A, C = th.C, Q = th.Q, R = th.R;
+        const double A2 = A * A, C2 = C * C;
+        const double rR = fast_rcp(R);
+        const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
+
+        auto e_at = [&](int j) {
+            double e = Yat(j);
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], Vat(j, q_), e);
+            return e;
+        };
+        auto bu_at = [&](int j) {
+            double bu = 0.0;
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
+            return bu;
+        };
+
+        // ------------------------------------------------ F1: compose this lane's step matrices;
+        // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
+        PMat M;
+        M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
+        if constexpr (DENSE) {
+            // Every step has the same 2x2 block Bm = [[alpha, Q],[C2R, 1]]: the chunk's block is a
+            // power of it (binary exponentiation) and only the third row needs the per-step
+            // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
+            // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
+            // power of two c = 2^-k that brings its largest block entry into [0.5, 1) (projective
+            // coordinates are scale free; alpha^31 alone could leave the double range when R is
+            // tiny): entries of Bm'^n stay within [2^-2n, 2^n].  The row (a, b, r) is carried as
+            // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
+            // r c <- (r c) A'.
+            const double mx = fmax(fmax(alpha, Q), fmax(C2R, 1.0));
+            const int ke = -__builtin_amdgcn_frexp_exp(mx);
+            const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
+            const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;
+            double p00 = al_, p01 = Q_, p10 = C2R_, p11 = c;        // running square Bm'^(2^bit)
+            double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm'^(L-1)
+            bool have = false;
+#pragma unroll
+            for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+                if ((L - 1) & (1 << bit)) {
+                    if (!have) { q00 = p00; q01 = p01; q10 = p10; q11 = p11; have = true; }
+                    else {
+                        const double t00 = fma(q00, p00, q01 * p10), t01 = fma(q00, p01, q01 * p11);
+                        const double t10 = fma(q10, p00, q11 * p10), t11 = fma(q10, p01, q11 * p11);
+                        q00 = t00; q01 = t01; q10 = t10; q11 = t11;
+                    }
+                }
+                if ((2 << bit) <= L - 1) {
+                    const double t00 = fma(p00, p00, p01 * p10), t01 = fma(p00, p01, p01 * p11);
+                    const double t10 = fma(p10, p00, p11 * p10), t11 = fma(p10, p01, p11 * p11);
+                    p00 = t00; p01 = t01; p10 = t10; p11 = t11;
+                }
+            }
+            // Bm'^L = Bm'^(L-1) * Bm'
+            const double r00 = fma(q00, al_, q01 * C2R_), r01 = fma(q00, Q_, q01 * c);
+            const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
+            if (act) {
+                double ra = 0.0, rb = 0.0, rcc = c;
+                auto row = [&](int j) {
+                    const double e = e_at(j), bu = bu_at(j);
+                    gv_[j] = e; Jv[j] = bu;
+                    const double s20 = fma(bu, C2R, ACR * e);
+                    const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
+                    rb = fma(rb, c, fma(ra, Q_, rcc * bu));
+                    ra = na;
+                    rcc *= A_;
+                };
+                if (tail) row(L - 1);
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) row(j);
+                M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
+                M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
+                M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
+                prenorm(M);
+            }
+        } else if (act) {
+            auto f1 = [&](int j) {
+                const bool o = (obsmask >> j) & 1u;
+                const double e = e_at(j), bu = bu_at(j);
+                gv_[j] = e; Jv[j] = bu;
+                const double a00 = o ? alpha : A2;
+                const double g = o ? C2R : 0.0;
+                const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
+                if (j == 0) {
+                    M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
+                } else {
+                    M = pstep(a00, Q, g, s20, bu, A, M);
+                }
+                if ((j & 15) == 15 && j < L - 2) prenorm(M);
+            };
+#pragma unroll
+            for (int j = 0; j < L - 1; j++) f1(j);
+            if (tail) f1(L - 1);
+            prenorm(M);
+        }
+
+        // ------------------------------------------------ forward scan over the half's 32 lanes
+        M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
+        M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
+        M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
+        prenorm(M);
+        M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
+        M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+        // exit state of this lane's chunk, then the entry state = exit state of the lane before
+        // (lane 0 of each half: the cell's initial state)
+        const double n_in = th.V1, d_in = 1.0, x_in = th.mu1;
+        double n_e = fma(M.m00, n_in, M.m01 * d_in);
+        double d_e = fma(M.m10, n_in, M.m11 * d_in);
+        double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
+        n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
+        d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
+        x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
+        if (vl == 0) { n_e = n_in; d_e = d_in; x_e = x_in; }
+        double Xp, Vp;
+        {
+            const double rd = fast_rcp(d_e);
+            Vp = n_e * rd;
+            Xp = x_e * rd;
+        }
+
+        // ------------------------------------------------ F2: serial re-run from the exact entry
+        double likq = 0.0, sprod = 1.0, Xu = 0.0, Vu = 0.0;
+        int sexp = 0, sneg = 0;
+        double sg = fma(C2, Vp, R);
+        double r0 = fast_rcp(sg);
+        auto f2 = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            const double e = gv_[j], bu = Jv[j];       // left there by F1
+            const double r = o ? r0 : 0.0;
+            const double sl = o ? sg : 1.0;
+            sprod *= sl;
+            sneg |= __double2hiint(sl);
+            if ((j & 7) == 7) {
+                sexp += __builtin_amdgcn_frexp_exp(sprod);
+                sprod = __builtin_amdgcn_frexp_mant(sprod);
+            }
+            const double w = Vp * r;
+            const double K = C * w;                    // src/EM.cpp:86
+            if (DENSE) Vu = R * w;                     // :88
+            else Vu = fma(-(C2 * w), Vp, Vp);
+            const double dl = fma(-C, Xp, e);
+            Xu = fma(K, dl, Xp);                       // :87
+            likq = fma(dl * r, dl, likq);              // :122
+            const double Vp1 = fma(A2, Vu, Q);         // :76
+            const double Xp1 = fma(A, Xu, bu);         // :74
+            sg = fma(C2, Vp1, R);
+            const double z = fast_rcp(sg * Vp1);
+            const double rp1 = sg * z;
+            r0 = Vp1 * z;
+            const double AVu = A * Vu;
+            double J = AVu * rp1;                      // :100
+            double g = fma(-J, Xp1, Xu);
+            double h = fma(-J, AVu, Vu);
+            if (j >= L - 2) {
+                // step T-1 starts the backward recursion: J = 0, g = Xu, h = Vu, zero terminal value
+                const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
+                J = fin ? 0.0 : J;
+                g = fin ? Xu : g;
+                h = fin ? Vu : h;
+            }
+            Jv[j] = J; gv_[j] = g;
+            if (j < L - 1) hs[j * 64] = h; else hlast = h;
+            Xp = Xp1;
+            Vp = Vp1;
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        };
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < L - 1; j++) f2(j);
+            if (tail) f2(L - 1);
+        }
+        const double termLast = shfl_d(fma(Xu, Xu, Vu), hbase | lastLane);   // Xs^2 + Vs at T-1
+        const double lsp = fma((double)sexp, 0.69314718055994530942, log(sprod));
+
+        // ------------------------------------------------ B1: compose the reverse affine maps
+        double Pi = 1.0, G = 0.0, H = 0.0;
+        if (act) {
+            if (tail) {
+                const double J = Jv[L - 1];
+                G = gv_[L - 1]; H = hlast; Pi = J;
+            }
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) {
+                const double J = Jv[j];
+                G = fma(J, G, gv_[j]);
+                H = fma(J * J, H, hs[j * 64]);
+                Pi *= J;
+            }
+        }
+#define RSCAN_ROUND(n)                                                     \
+        {                                                                  \
+            const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
+            const double Gb = dppz<DPP_ROW_SHL(n)>(G);                     \
+            const double Hb = dppz<DPP_ROW_SHL(n)>(H);                     \
+            G = fma(Pi, Gb, G);                                            \
+            H = fma(Pi * Pi, Hb, H);                                       \
+            Pi *= Pb;                                                      \
+        }
+        RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+        {
+            // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
+            const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
+            const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
+            const int row = lane >> 4;
+            const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+            const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
+            G = fma(Pi, Gs, G);
+            H = fma(Pi * Pi, Hs, H);
+        }
+        // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
+        // chunk is the next lane's, and the zero terminal value for the half's last lane
+        double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+        double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
+        if (vl == 31) { Xn = 0.0; Vn = 0.0; }
+
+        // ------------------------------------------------ B2: serial reverse re-run + M-step sums
+        // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
+        // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
+        // steps, the LDS reads of the series batch freely).
+        double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0, aSxx = 0.0;
+        double aSxv[QQ], aTx1u[PP], aTux[PP];
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+        const double XnE = Xn;
+        auto b2a = [&](int j) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            const double J = Jv[j];
+            const double h = (j < L - 1) ? hs[j * 64] : hlast;
+            aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
+            const double Xs = fma(J, Xn, gv_[j]);       // :101
+            const double Vs = fma(J * J, Vn, h);        // :102
+            aPall += Vs;                                // :181,:183
+            if (!DENSE) aSxx += o ? Vs : 0.0;           // :152
+            gv_[j] = Xs;
+            Xn = Xs;
+            Vn = Vs;
+        };
+        auto b2b = [&](int j, bool top) {
+            const bool o = DENSE || ((obsmask >> j) & 1u);
+            const double Xs = gv_[j];
+            const double Xnx = top ? XnE : gv_[top ? j : j + 1];
+            aTx1x = fma(Xnx, Xs, aTx1x);                // :180
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) {
+                const double ut = Uat(j, p_);           // zero at t = T-1
+                aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
+                aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
+            }
+            aPall = fma(Xs, Xs, aPall);
+            const double xo = o ? Xs : 0.0;
+            aSyx = fma(Yat(j), xo, aSyx);               // :151
+            if (!DENSE) aSxx = fma(xo, xo, aSxx);
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
+            if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        };
+        if (act) {
+            if (tail) b2a(L - 1);
+            else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2a(j);
+            if (tail) b2b(L - 1, true);
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2b(j, false);
+        }
+        // Xn, Vn = Xs, Vs at the first step of this lane's chunk
+
+        // ------------------------------------------------ one reduction per half, M-step, stop rule
+        Sums<PP, QQ> S;
+        {
+            constexpr int NB = 5 + (DENSE ? 0 : 1);
+            constexpr int NR = NB + QQ + 2 * PP;
+            double red[NR];
+            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
+            if (!DENSE) red[5] = aSxx;
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) red[NB + q_] = aSxv[q_];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = aTx1u[p_]; red[NB + QQ + PP + p_] = aTux[p_]; }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) {
+                double t[NR];
+#pragma unroll
+                for (int i = 0; i < NR; i++) t[i] = __shfl_xor(red[i], d, 64);
+#pragma unroll
+                for (int i = 0; i < NR; i++) red[i] += t[i];
+            }
+            S.X0 = shfl_d(Xn, hbase);                // :218
+            S.V0 = shfl_d(Vn, hbase);                // :219
+            const double term0 = fma(S.X0, S.X0, S.V0);
+            const unsigned long long negm = __ballot(sneg < 0);
+            const bool neg = ((negm >> hbase) & 0xffffffffull) != 0;   // log of a negative Sigma
+            S.Syx = red[0]; S.Tx1x = red[1];
+            S.Sxx = DENSE ? red[2] : red[5];
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) S.Sxv[q_] = red[NB + q_];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { S.Tx1u[p_] = red[NB + QQ + p_]; S.Tux[p_] = red[NB + QQ + PP + p_]; }
+            S.Txx = red[2] - termLast;
+            S.Tx1x1 = red[2] - term0;
+            lik2 = lik1;
+            lik1 = lik;
+            lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;   // :113-124
+            if (neg) lik = NAN;
+        }
+        int abort_now = 0;
+        if (prm.abort && ((++wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
+            abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
+        if (alive && prm.liks && vl == 0) prm.liks[(long)cell * prm.niter + it] = lik;
+        it++;
+        bool stop = it >= prm.niter || abort_now;
+        if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;   // :272
+        if (alive && stop) {
+            // theta stays the one that produced this fit (:276-279)
+            if (vl == 0) {
+                store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+                if (prm.liks && prm.liks_nanfill)
+                    for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+                prm.n_iter[cell] = it;
+                prm.lik[cell] = lik;
+                prm.status[cell] = (abort_now && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
+            }
+            alive = false;
+            if constexpr (QUEUE) {
+                if (!abort_now) {
+                    int kn = 0;
+                    if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
+                    kn = __shfl(kn, hbase, 64);
+                    if (kn < nc) {
+                        alive = true;
+                        cell = c0 + kn;
+                        load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+                        it = 0;
+                        lik = NAN; lik1 = NAN; lik2 = NAN;
+                    }
+                }
+            }
+        } else {
+            mstep_update<PP, QQ, true>(th, S, (SeriesConstK)sc, T);
+        }
+    }
+}
+
+// One workgroup = up to 8 waves = up to 16 cells of ONE series.  Static: wave w owns cells
+// c0 + 2w, c0 + 2w + 1 of the block (nc of them).  QUEUE: (c0, nc) is the series' whole range and
+// every half pulls cells from the per-series counter.
+template <int PP, int QQ, int L, bool QUEUE>
+__global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr long IMG = pair_image_doubles(L, PP, QQ);
+    const int b = blockIdx.x;
+    const int s = prm.blk_series[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *gimg = prm.img2 + (long)s * prm.img2_stride;
+    for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+    __syncthreads();
+    const SeriesConst *sc = prm.sc + s;
+    if (sc->status != 0) {
+        // singular Svv / Tuu: every cell of the block (static) or of the series (queue: block 0
+        // of the series' blocks is enough, the others repeat the same writes) ends with status 2
+        const int P = 6 + prm.p + prm.q;
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            const int cell = c0 + c;
+            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+            prm.n_iter[cell] = 0;
+            if (prm.liks && prm.liks_nanfill)
+                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            prm.lik[cell] = NAN;
+            prm.status[cell] = 2;
+        }
+        return;
+    }
+    if (!QUEUE && 2 * wave >= nc) return;    // whole wave leaves; no barrier follows
+    double *hs = smem + IMG + (long)wave * pair_strip_doubles(L) + lane;
+    const bool dense = sc->n_obs == prm.T;
+    if (dense) em_pair_body<PP, QQ, L, true, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
+    else em_pair_body<PP, QQ, L, false, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
+}
+
+struct PairPlan {
+    int L = 0;
+    int wpb = 0;        // waves per workgroup (2 cells each)
+    bool ok = false;
+};
+PairPlan pair_plan(int T, int PP, int QQ);
+
+template <int L>
+hipError_t launch_em_pair_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,
+                            hipStream_t stream);

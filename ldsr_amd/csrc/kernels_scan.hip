@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "em_scan_impl.h"
+#include "em_pair_impl.h"
 #include "ldsr_kernels.h"
 
 static const size_t kLdsBytes = 160 * 1024;
@@ -89,4 +90,46 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
         default: return hipErrorInvalidValue;
     }
 #undef CASE_LW
+}
+
+// ---- two cells per wave (em_pair_impl.h) -------------------------------------------------------
+// Smallest compiled chunk length with L (L-1) <= T <= 32 L; as many waves per workgroup (two cells
+// each) as the 160 KiB of a CU hold next to the 32-lane series image, at least 6 of the wanted 8.
+PairPlan pair_plan(int T, int PP, int QQ) {
+    PairPlan p;
+    if (PP > 2 || QQ > 4 || T < 2) return p;
+    static const int Ls[] = {26, 32};
+    for (int L : Ls)
+        if (T <= 32 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
+    if (!p.L) return p;
+    const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ) * sizeof(double);
+    const size_t strip = (size_t)pair_strip_doubles(p.L) * sizeof(double);
+    if (img + 6 * strip > kLdsBytes) return p;
+    p.wpb = (int)((kLdsBytes - img) / strip);
+    if (p.wpb > 8) p.wpb = 8;
+    p.ok = true;
+    return p;
+}
+
+bool em_pair_supported(int T, int PP, int QQ) { return pair_plan(T, PP, QQ).ok; }
+int em_pair_cells_per_block(int T, int PP, int QQ) { return 2 * pair_plan(T, PP, QQ).wpb; }
+void em_pair_layout(int T, int PP, int QQ, int *L, long *img_doubles) {
+    const PairPlan p = pair_plan(T, PP, QQ);
+    *L = p.L;
+    *img_doubles = p.ok ? pair_image_doubles(p.L, PP, QQ) : 0;
+}
+void em_pair_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len) {
+    const PairPlan p = pair_plan(T, PP, QQ);
+    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %s>", PP, QQ, p.L, queue ? "true" : "false");
+}
+
+hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
+                          hipStream_t stream) {
+    const PairPlan p = pair_plan(prm.T, PP, QQ);
+    if (!p.ok || !prm.img2) return hipErrorInvalidValue;
+    switch (p.L) {
+        case 26: return launch_em_pair_L<26>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 32: return launch_em_pair_L<32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        default: return hipErrorInvalidValue;
+    }
 }

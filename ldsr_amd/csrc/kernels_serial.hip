@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
         }
     }
-    if (prm.img) {
-        // chunk-transposed image of the scan kernel (layout: em_scan_impl.h): the K = 1+PP+QQ
-        // values of a step in pairs, pair m of step j of virtual lane l at
-        // [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where missing / beyond the chunk / padding
-        double *im = prm.img + (long)s * prm.img_stride;
-        const int L = prm.L, NL = prm.NL, K = 1 + PP + QQ, KP = (K + 1) / 2;
+    // chunk-transposed images (layout: em_scan_impl.h): the K = 1+PP+QQ values of a step in
+    // pairs, pair m of step j of virtual lane l at [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where
+    // missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
+    // kernel's (32 lanes, its own chunk length).
+    auto build_image = [&](double *im, int L, int NL) {
+        const int K = 1 + PP + QQ, KP = (K + 1) / 2;
         const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
         for (int e = tid; e < NL * L * KP * 2; e += 256) {
             const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             }
             im[e] = val;
         }
-    }
+    };
+    if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL);
+    if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, 32);
     // identity / zero padding of the statistics
     for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
         const double id = ((i / LDSR_MAXPQ) == (i % LDSR_MAXPQ)) ? 1.0 : 0.0;

@@ -346,19 +346,32 @@ struct Carver {
 };
 
 // ---- algorithm choice / workspace layout -------------------------------------------------------
+// LDSR_PAIR=0 in the environment keeps AUTO off the two-cells-per-wave kernel (same-box A/B runs)
+static bool pair_enabled() {
+    static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int resolve_algo(int algo, int T, int PP, int QQ) {
-    if (algo == LDSR_ALGO_AUTO) return em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
+    if (algo == LDSR_ALGO_AUTO) {
+        if (pair_enabled() && em_pair_supported(T, PP, QQ)) return LDSR_ALGO_PAIR;
+        return em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
+    }
     return algo;
 }
 
+// cells per workgroup of the EM launch (the workspace's block table is sized for the scan
+// kernel's value, the smallest of the three, whenever its image is built)
 static int cells_per_block(int algo, int T, int PP, int QQ) {
+    if (algo == LDSR_ALGO_PAIR) return em_pair_cells_per_block(T, PP, QQ);
     return algo == LDSR_ALGO_SCAN ? em_scan_cells_per_block(T, PP, QQ) : 64;
 }
 
 struct WsLayout {
-    size_t sc, yp, yz, up, vp, img, blk, soc, queue, scratch, total;
+    size_t sc, yp, yz, up, vp, img, img2, blk, soc, queue, scratch, total;
     long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
-    int max_blocks, img_L, img_NL;
+    long img2_stride;                  // pair kernel's image (0 = none)
+    int max_blocks, img_L, img_NL, img2_L;
 };
 
 static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, int n_cells,
@@ -375,6 +388,10 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     // whose shape the scan kernel supports: the winners' fit then runs on the scan kernel)
     em_scan_layout(T, PP, QQ, &L.img_L, &L.img_NL, &L.img_stride);
     L.img = o; o = align256(o + sizeof(double) * (size_t)L.img_stride * n_series);
+    L.img2_stride = 0; L.img2_L = 0;
+    if (algo == LDSR_ALGO_PAIR) em_pair_layout(T, PP, QQ, &L.img2_L, &L.img2_stride);
+    L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
+    if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
@@ -414,6 +431,7 @@ extern "C" size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ)) return 0;
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ)) return 0;
     // the layout for shared_uv = 0 is an upper bound for shared_uv = 1
     return ws_layout(n_series, T, PP, QQ, 0, n_cells, algo, cells_per_block(algo, T, PP, QQ)).total;
 }
@@ -432,6 +450,9 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
         if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
+    } else if (algo == LDSR_ALGO_PAIR) {
+        if (!em_pair_supported(T, PP, QQ)) return -1;
+        if (buf && len) em_pair_kernel_name(T, PP, QQ, tol > 0.0, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
         if (buf && len) em_serial_kernel_name(T, PP, QQ, buf, len);
     } else {
@@ -457,6 +478,9 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.img_stride = L.img_stride;
     pp.L = L.img_L;
     pp.NL = L.img_NL;
+    pp.img2 = L.img2_stride ? (double *)(ws + L.img2) : nullptr;
+    pp.img2_stride = L.img2_stride;
+    pp.L2 = L.img2_L;
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -480,9 +504,12 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (n_cells == 0) return LDSR_OK;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     algo = resolve_algo(algo, T, PP, QQ);
-    if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN) return fail(LDSR_EINVAL, "unknown algo");
+    if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR)
+        return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ))
+        return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 650 <= T <= 1024 (a compiled chunk length), p <= 2 and q <= 4");
     const int cpb = cells_per_block(algo, T, PP, QQ);
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo, cpb);
     if (workspace_bytes < L.total)
@@ -499,7 +526,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // of the block).  Work queue (scan kernel, tol > 0): (series, first cell of the SERIES, n
     // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
     // converges early takes the next one instead of idling.
-    const bool use_queue = algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol);
+    const bool use_queue = (algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol)) ||
+                           (algo == LDSR_ALGO_PAIR && tol > 0.0);
     std::vector<int> bs, bc, bn;
     for (int s = 0; s < n_series; s++)
         for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
@@ -536,6 +564,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.v_stride = shared_uv ? 0 : (long)T * QQ;
     prm.img = (const double *)(ws + L.img);
     prm.img_stride = L.img_stride;
+    prm.img2 = L.img2_stride ? (const double *)(ws + L.img2) : nullptr;
+    prm.img2_stride = L.img2_stride;
     prm.fitX = prm.fitY = prm.fitV = prm.fitJ = prm.pen = nullptr;
     prm.lambda = 0.0;
     prm.stdlik = 1;
@@ -551,7 +581,9 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.scratch_stride = L.scratch_stride;
     int slot;
     HIPCHK(prof_begin(device, stream, &slot));
-    if (algo == LDSR_ALGO_SCAN)
+    if (algo == LDSR_ALGO_PAIR)
+        HIPCHK(launch_em_pair(prm, PP, QQ, n_blocks, use_queue, stream));
+    else if (algo == LDSR_ALGO_SCAN)
         HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
     else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));

@@ -175,6 +175,8 @@ struct EmParams {
     long u_stride, v_stride; // doubles per series (0 when shared)
     const double *img;       // scan kernel: [n_series] chunk-transposed series images (see em_scan_impl.h)
     long img_stride;         // doubles per series image
+    const double *img2;      // pair kernel (em_pair_impl.h): [n_series] images in its 32-lane layout, or null
+    long img2_stride;
     const SeriesConst *sc;   // [n_series]
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
