@@ -210,6 +210,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         int sexp = 0, sneg = 0;
         double sg = fma(C2, Vp, R);
         double r0 = fast_rcp(sg);
+        // reverse affine composite of the lane's chunk (B1 of em_scan_impl.h), accumulated in time
+        // order while the steps are produced: (Pi, G, H) o step_j -- no second pass over h_t
+        double Pi = 1.0, G = 0.0, H = 0.0;
         auto f2 = [&](int j) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
             const double e = gv_[j], bu = Jv[j];       // left there by F1
@@ -247,6 +250,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             }
             Jv[j] = J; gv_[j] = g;
             if (j < L - 1) hs[j * 64] = h; else hlast = h;
+            G = fma(Pi, g, G);
+            H = fma(Pi * Pi, h, H);
+            Pi *= J;
             Xp = Xp1;
             Vp = Vp1;
             if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -259,21 +265,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         const double termLast = shfl_d(fma(Xu, Xu, Vu), hbase | lastLane);   // Xs^2 + Vs at T-1
         const double lsp = fma((double)sexp, 0.69314718055994530942, log(sprod));
 
-        // ------------------------------------------------ B1: compose the reverse affine maps
-        double Pi = 1.0, G = 0.0, H = 0.0;
-        if (act) {
-            if (tail) {
-                const double J = Jv[L - 1];
-                G = gv_[L - 1]; H = hlast; Pi = J;
-            }
-#pragma unroll
-            for (int j = L - 2; j >= 0; j--) {
-                const double J = Jv[j];
-                G = fma(J, G, gv_[j]);
-                H = fma(J * J, H, hs[j * 64]);
-                Pi *= J;
-            }
-        }
+        // ------------------------------------------------ reverse scan of the chunk composites
 #define RSCAN_ROUND(n)                                                     \
         {                                                                  \
             const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
