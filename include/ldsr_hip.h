@@ -83,7 +83,7 @@ extern "C" {
 #define LDSR_ALGO_SCAN 2   /* one to four wavefronts per cell, parallel-in-time scans (T <= 8192,
                               p, q <= 8); AUTO picks it whenever it applies and PAIR does not */
 #define LDSR_ALGO_PAIR 3   /* the same scans with TWO cells per wavefront (one per 32-lane half):
-                              650 <= T <= 1024, p <= 2, q <= 4; AUTO's first choice there */
+XX */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);

@@ -1,5 +1,5 @@
-// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of up to
-// 1024 steps with narrow inputs (T <= 32 L, L <= 32, padded p <= 2, q <= 4).
+// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of 513 to
+// 1024 steps with narrow inputs (T <= 32 L, 17 <= L <= 32, padded p <= 2, q <= 4).
 //
 // Why.  In em_scan_kernel (one cell per 64-lane wave, em_scan_impl.h) half of the ~1500 VALU
 // instructions of an EM iteration at T = 1000 do not depend on the chunk length: the two
@@ -110,12 +110,13 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             // power of it (binary exponentiation) and only the third row needs the per-step
             // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
             // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
-            // power of two c = 2^-k that brings its largest block entry into [0.5, 1) (projective
-            // coordinates are scale free; alpha^31 alone could leave the double range when R is
-            // tiny): entries of Bm'^n stay within [2^-2n, 2^n].  The row (a, b, r) is carried as
+            // power of two c = 2^-k with max(alpha, 1) c in [0.5, 1) (projective coordinates are
+            // scale free; alpha^31 alone could leave the double range when R is tiny).  Bm is
+            // positive with alpha >= Q C2R, so its Perron root lies in [max(alpha, 1), 2 max(alpha, 1)]
+            // and the powers of Bm' neither overflow nor underflow.  The row (a, b, r) is carried as
             // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
             // r c <- (r c) A'.
-            const double mx = fmax(fmax(alpha, Q), fmax(C2R, 1.0));
+            const double mx = fmax(alpha, 1.0);
             const int ke = -__builtin_amdgcn_frexp_exp(mx);
             const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
             const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;

@@ -97,9 +97,9 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 // each) as the 160 KiB of a CU hold next to the 32-lane series image, at least 6 of the wanted 8.
 PairPlan pair_plan(int T, int PP, int QQ) {
     PairPlan p;
-    if (PP > 2 || QQ > 4 || T < 2) return p;
-    static const int Ls[] = {26, 32};
-    for (int L : Ls)
+    if (PP > 2 || QQ > 4 || T <= 512) return p;
+    // every chunk length from 17 (T = 513) to 32 (T = 1024): the shortest one wastes no lanes
+    for (int L = 17; L <= 32; L++)
         if (T <= 32 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
     if (!p.L) return p;
     const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ) * sizeof(double);
@@ -128,7 +128,21 @@ hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int n_blocks, boo
     const PairPlan p = pair_plan(prm.T, PP, QQ);
     if (!p.ok || !prm.img2) return hipErrorInvalidValue;
     switch (p.L) {
+        case 17: return launch_em_pair_L<17>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 18: return launch_em_pair_L<18>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 19: return launch_em_pair_L<19>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 20: return launch_em_pair_L<20>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 21: return launch_em_pair_L<21>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 22: return launch_em_pair_L<22>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 23: return launch_em_pair_L<23>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 24: return launch_em_pair_L<24>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 25: return launch_em_pair_L<25>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 26: return launch_em_pair_L<26>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 27: return launch_em_pair_L<27>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 28: return launch_em_pair_L<28>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 29: return launch_em_pair_L<29>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 30: return launch_em_pair_L<30>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 31: return launch_em_pair_L<31>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 32: return launch_em_pair_L<32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         default: return hipErrorInvalidValue;
     }
