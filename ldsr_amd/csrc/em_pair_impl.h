@@ -264,7 +264,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             if (tail) f2(L - 1);
         }
         const double termLast = shfl_d(fma(Xu, Xu, Vu), hbase | lastLane);   // Xs^2 + Vs at T-1
-        const double lsp = fma((double)sexp, 0.69314718055994530942, log(sprod));
+        const double lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
 
         // ------------------------------------------------ reverse scan of the chunk composites
 #define RSCAN_ROUND(n)                                                     \

@@ -668,7 +668,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         // The two likelihood sums ride along with the M-step sums in ONE wave reduction at the end
         // of the iteration; the backward sweep of the final iteration is therefore redundant
         // (1 of n_iter sweeps) but every iteration saves 6 dependent cross-lane rounds.
-        const double lsp = fma((double)sexp, 0.69314718055994530942, log(sprod));
+        const double lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
 
         // ------------------------------------------------ B1: compose the reverse affine maps
         auto b1 = [&](int j) {

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
         if (v) ok = invert_small(sc.Svv_inv, inv_ws, q) && ok;
         if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p) && ok;
         sc.status = ok ? 0 : 2;
+        sc.rn_obs = 1.0 / (double)sc.n_obs;
+        sc.rTm1 = 1.0 / (double)(T - 1);
         for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
             double a = 0.0;
             for (int ll = 0; ll < LDSR_MAXPQ; ll++) a += sc.Svv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];

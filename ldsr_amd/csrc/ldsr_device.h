@@ -23,6 +23,7 @@ struct SeriesConst {
     double wv[LDSR_MAXPQ];                  // Svv^{-1} Syv
     double Svv_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_obs v_t v_t')^{-1}   (:161), identity padded
     double Tuu_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_{t<T-1} u_t u_t')^{-1} (:193), identity padded
+    double rn_obs, rTm1;                      // 1 / n_obs, 1 / (T - 1): the divisors of R (:177) and Q (:210)
 };
 
 template <int PP, int QQ>
@@ -77,14 +78,40 @@ __device__ __forceinline__ void store_theta(const Theta<PP, QQ> &th, double *__r
     g[5 + p + q] = th.V1;
 }
 
-// 1/x to ~1 ulp: v_rcp_f64 seed (24 bits) + two Newton steps; 99.98 % of results are the
-// correctly rounded reciprocal, max error 1.1e-16 (tools/rcp_probe.hip on MI355X).
+// 1/x to ~1 ulp: v_rcp_f64 seed (24 bits, e = 1 - x r <= 4.6e-8) + ONE third-order step
+// r (1 + e + e^2) -- three FMAs where two Newton steps take four, same result quality: 99.98 % of
+// results are the correctly rounded reciprocal, max error 1.1e-16 (tools/rcp_probe.hip on MI355X;
+// the neglected e^3 is 1e-22).  fp64 FMAs are what the EM kernels' time is made of
+// (tools/valu_rate_probe.hip: 2.06 ns per wave-instruction per SIMD against 0.85 for 32-bit ops).
 __device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+
+// log(x) of a finite positive double as (exponent, mantissa): x = m 2^k with m in [sqrt(1/2),
+// sqrt(2)), log x = k ln 2 + log m, and log m = f - (f^2/2 - s (f^2/2 + R(s^2))) with f = m - 1,
+// s = f / (2 + f): the classic fdlibm e_log.c scheme and its degree-7 minimax R (error < 1 ulp),
+// restated without the special cases -- the argument here is the folded product of the innovation
+// variances (em_scan_impl.h), and a zero / negative / non-finite one only has to give a
+// non-finite likelihood (0 -> -inf, NaN -> NaN; a negative Sigma is flagged separately).
+// ~25 fp64 operations where the library log takes ~50 plus its case analysis.
+__device__ __forceinline__ double log_pos(double x) {
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s_ = f * fast_rcp(2.0 + f);
+    const double z = s_ * s_, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double hfsq = 0.5 * f * f;
+    const double lm = f - (hfsq - s_ * (hfsq + (t1 + t2)));
+    const double r = fma((double)k, 0.69314718055994530942, lm);
+    return x > 0.0 && x < INFINITY ? r : (x == 0.0 ? -INFINITY : (x > 0.0 ? INFINITY : NAN));
 }
 
 // Closed-form M-step (src/EM.cpp:139-229).  The reference solves
@@ -128,7 +155,7 @@ __device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, Q
         racc = fma(-d, sc->Syv[k], racc);
     }
     th.C = C;
-    th.R = FAST ? racc * fast_rcp((double)sc->n_obs) : racc / (double)sc->n_obs;
+    th.R = FAST ? racc * sc->rn_obs : racc / (double)sc->n_obs;
 
     double zu[PP], ru[PP];
 #pragma unroll
@@ -158,7 +185,7 @@ __device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, Q
         qacc = fma(-b, S.Tx1u[k], qacc);
     }
     th.A = A;
-    th.Q = FAST ? qacc * fast_rcp((double)(T - 1)) : qacc / (double)(T - 1);
+    th.Q = FAST ? qacc * sc->rTm1 : qacc / (double)(T - 1);
     th.mu1 = S.X0;
     th.V1 = S.V0;
 }
