@@ -360,13 +360,13 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             for (int q_ = 0; q_ < QQ; q_++) red[NB + q_] = aSxv[q_];
 #pragma unroll
             for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = aTx1u[p_]; red[NB + QQ + PP + p_] = aTux[p_]; }
+            // recursive halving over the half's 32 lanes (em_scan_impl.h), then every lane fetches
+            // the totals from their home lanes of its own half
+            red_rounds<NR, 16>(red, lane);
+            {
+                const double t0 = red[0];
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) {
-                double t[NR];
-#pragma unroll
-                for (int i = 0; i < NR; i++) t[i] = __shfl_xor(red[i], d, 64);
-#pragma unroll
-                for (int i = 0; i < NR; i++) red[i] += t[i];
+                for (int i = 0; i < NR; i++) red[i] = shfl_d(t0, hbase | red_home(i, NR, 32));
             }
             S.X0 = shfl_d(Xn, hbase);                // :218
             S.V0 = shfl_d(Vn, hbase);                // :219

@@ -68,20 +68,51 @@ __device__ __forceinline__ double uniform_d(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// All-reduce N independent sums with ONE dependent chain of 6 cross-lane rounds: every round
-// issues all N exchanges before the N adds (a per-value butterfly would serialise 6*N LDS
-// round-trips).  The summation tree is fixed, so results are run-to-run deterministic and
-// identical in every lane (fp add is commutative).
+// Sum N independent per-lane values over the WIDTH (64 or 32) lanes of a group by recursive
+// halving: in the round with exchange distance D a lane keeps one half of its live values, hands
+// the other half to its partner (lane ^ D) and adds what it receives, so the number of live values
+// per lane halves every round -- N/2 + N/4 + ... ~ N exchanges and fp64 adds in all, where a
+// butterfly all-reduce of every value (round 1's form) took N log2(WIDTH) of each (cfg3: 25 instead
+// of 150 adds and 50 instead of 300 ds_bpermute per EM iteration).  fp64 adds are what the kernels'
+// time is made of; the selects that pick the halves are 32-bit moves.  The total of value v ends in
+// slot 0 of lane red_home(v) of the group; callers broadcast it from there (v_readlane, or
+// ds_bpermute where the two halves of a wave hold different cells).  The summation tree is
+// fixed: results are run-to-run deterministic and identical in every lane.
+__host__ __device__ constexpr int red_home(int v, int n, int width) {
+    int lane = 0;
+    for (int d = width / 2; d >= 1; d >>= 1) {
+        const int nk = (n + 1) / 2;
+        if (v >= nk) { lane |= d; v -= nk; }
+        n = nk;
+    }
+    return lane;
+}
+template <int N, int D>
+__device__ __forceinline__ void red_rounds(double *x, int lane) {
+    if constexpr (D >= 1) {
+        constexpr int NK = (N + 1) / 2, NF = N - NK;
+        const bool up = (lane & D) != 0;
+        double snd[NK], kp[NK];
+#pragma unroll
+        for (int i = 0; i < NK; i++) {
+            const double hi = (i < NF) ? x[NK + i] : 0.0;   // (an odd count leaves one padded slot)
+            snd[i] = up ? x[i] : hi;
+            kp[i] = up ? hi : x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NK; i++) snd[i] = __shfl_xor(snd[i], D, 64);
+#pragma unroll
+        for (int i = 0; i < NK; i++) x[i] = kp[i] + snd[i];
+        red_rounds<NK, D / 2>(x, lane);
+    }
+}
+// wave-uniform totals of x[0..N) over all 64 lanes (left in x, the same in every lane)
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
+    red_rounds<N, 32>(x, (int)(threadIdx.x & 63));
+    const double t0 = x[0];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        double t[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) t[i] = __shfl_xor(x[i], d, 64);
-#pragma unroll
-        for (int i = 0; i < N; i++) x[i] += t[i];
-    }
+    for (int v = 0; v < N; v++) x[v] = readlane_d(t0, red_home(v, N, 64));   // constant lanes after unrolling
 }
 
 // Structured 3x3 step / composite matrix [[m00 m01 0],[m10 m11 0],[m20 m21 m22]].
