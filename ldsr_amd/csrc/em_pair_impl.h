@@ -1,5 +1,6 @@
 // em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of 513 to
-// 1024 steps with narrow inputs (T <= 32 L, 17 <= L <= 32, padded p <= 2, q <= 4).
+// 1024 steps with narrow inputs (T <= 32 L, 17 <= L <= 32, padded p, q <= 4; kernels_scan.hip
+// pair_plan() has the exact ranges).
 //
 // Why.  In em_scan_kernel (one cell per 64-lane wave, em_scan_impl.h) half of the ~1500 VALU
 // instructions of an EM iteration at T = 1000 do not depend on the chunk length: the two

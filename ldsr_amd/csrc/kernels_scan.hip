@@ -93,20 +93,22 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 }
 
 // ---- two cells per wave (em_pair_impl.h) -------------------------------------------------------
-// Smallest compiled chunk length with L (L-1) <= T <= 32 L; as many waves per workgroup (two cells
-// each) as the 160 KiB of a CU hold next to the 32-lane series image, at least 6 of the wanted 8.
+// Smallest chunk length with L (L-1) <= T <= 32 L.  The kernel pays off only with two waves per
+// SIMD: eight waves per workgroup (one workgroup fills a CU's LDS), i.e. the 32-lane series image
+// and eight strips must fit 160 KiB -- (1,2): every L; (1,4): L <= 29; (2,4), (4,2): L <= 27;
+// (4,4): L <= 25.  Same-box A/B at 8192 cells: with 7 or 6 waves per CU (and the coarser workgroup
+// count) it is 20-25 % SLOWER than the one-cell-per-wave kernel, with 8 it is 10-15 % faster.
 PairPlan pair_plan(int T, int PP, int QQ) {
     PairPlan p;
-    if (PP > 2 || QQ > 4 || T <= 512) return p;
+    if (PP > 4 || QQ > 4 || T <= 512) return p;
     // every chunk length from 17 (T = 513) to 32 (T = 1024): the shortest one wastes no lanes
     for (int L = 17; L <= 32; L++)
         if (T <= 32 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
     if (!p.L) return p;
     const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ) * sizeof(double);
     const size_t strip = (size_t)pair_strip_doubles(p.L) * sizeof(double);
-    if (img + 6 * strip > kLdsBytes) return p;
-    p.wpb = (int)((kLdsBytes - img) / strip);
-    if (p.wpb > 8) p.wpb = 8;
+    if (img + 8 * strip > kLdsBytes) return p;
+    p.wpb = 8;
     p.ok = true;
     return p;
 }

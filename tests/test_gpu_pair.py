@@ -77,11 +77,14 @@ def test_every_chunk_length_matches_oracle(eng, T, mask):
         _check(r, ref, "T=%d %s tol=%g" % (T, mask, tol))
 
 
-@pytest.mark.parametrize("p,q", [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4)])
+@pytest.mark.parametrize("p,q", [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4),
+                                 (3, 1), (4, 2), (3, 3), (4, 4)])
 @pytest.mark.parametrize("mask", ["dense", "holes", "head"])
 def test_every_compiled_width(eng, p, q, mask):
     from ldsr_amd import synth
-    T = 813 if (p + q) % 2 else 1000
+    pad = lambda n: 1 if n <= 1 else 2 if n <= 2 else 4
+    KP = (1 + pad(p) + pad(q) + 1) // 2          # 16-byte value pairs per step of the series image
+    T = {2: 1000, 3: 928, 4: 864, 5: 800}[KP]    # the longest series that leaves room for 8 waves per CU
     y, u, v = _series(T, p, q, 7 * p + q, mask)
     th0 = synth.make_init_packed(p, q, 48, seed=p * 10 + q)
     ref = _oracle(y, u.T[None], v.T[None], np.zeros(48), th0, 400, 1e-5)
@@ -190,7 +193,7 @@ def test_singular_series_and_bad_shapes(eng):
         assert np.all(r["status"] == 2) and np.all(np.isnan(r["theta"])) and np.all(r["n_iter"] == 0)
         assert np.all(np.isnan(r["liks"]))
     # shapes outside the kernel: explicit PAIR is an error, AUTO goes elsewhere
-    for (T2, p2, q2) in ((512, 1, 2), (1025, 1, 2), (1000, 3, 2), (1000, 1, 5)):
+    for (T2, p2, q2) in ((512, 1, 2), (1025, 1, 2), (1000, 5, 2), (1000, 1, 5), (1000, 1, 4), (900, 4, 4)):
         assert _plan_name(T2, p2, q2, 0.0, PAIR)[0] == -1
         a, name = _plan_name(T2, p2, q2, 0.0, 0)
         assert a in (1, 2) and "em_pair" not in name
