@@ -446,7 +446,11 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
         return -1;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    const bool was_auto = algo == LDSR_ALGO_AUTO;
     algo = resolve_algo(algo, T, PP, QQ);
+    // what ldsr_em_batch_device runs (the host-pointer entries additionally take the pair kernel
+    // with tol > 0 when every series is fully observed)
+    if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0) algo = LDSR_ALGO_SCAN;
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
         if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
@@ -493,7 +497,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 int niter, double tol, int algo, double *d_theta, double *d_lik,
                                 int *d_n_iter, int *d_status, double *d_liks, int liks_nanfill,
                                 void *d_workspace, size_t workspace_bytes,
-                                const int *abort_flag = nullptr) {
+                                const int *abort_flag = nullptr, int dense_hint = -1) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -503,7 +507,16 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const int n_cells = cell_offsets[n_series];
     if (n_cells == 0) return LDSR_OK;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    const bool was_auto = algo == LDSR_ALGO_AUTO;
     algo = resolve_algo(algo, T, PP, QQ);
+    const int algo_layout = algo;       // what the workspace was sized and laid out for
+    // AUTO with early stopping: the pair kernel couples two cells per wave and sixteen per
+    // workgroup (= per CU), so widely different iteration counts cost it more than they cost the
+    // scan kernel's four-cell workgroups.  Measured (converged runs, tol = 1e-5): fully observed
+    // series (cells stop after 28..63 iterations) pair +8..12 %; masked series (4..176, cfg5 up
+    // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
+    // series known to be fully observed (the host-pointer entries look; dense_hint).
+    if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR)
         return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
@@ -511,7 +524,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 513 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
     const int cpb = cells_per_block(algo, T, PP, QQ);
-    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo, cpb);
+    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
+                                 cells_per_block(algo_layout, T, PP, QQ));
     if (workspace_bytes < L.total)
         return fail(LDSR_EINVAL, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (((size_t)d_workspace & 255) != 0) return fail(LDSR_EINVAL, "workspace must be 256-byte aligned");
@@ -698,6 +712,7 @@ static int launch_smoother(int device, hipStream_t stream, int T, int p, int q, 
 struct Slice {
     // inputs (host pointers already offset to the slice; `off` are local cell offsets)
     int device = 0, n_series = 0, T = 0, p = 0, q = 0, shared_uv = 0, niter = 0, algo = 0;
+    int dense_hint = -1;     // 1: every y_t of every series is finite (AUTO's kernel choice with tol > 0)
     double tol = 0.0;
     const double *y = nullptr, *u = nullptr, *v = nullptr, *theta0 = nullptr;
     std::vector<int> off;
@@ -811,6 +826,12 @@ static int slice_run(Slice &S) {
     // stage inputs
     char *pin = A->pin + S.p_in;
     memcpy(pin + (S.d_y - S.d_in), S.y, sizeof(double) * (size_t)S.n_series * T);
+    {
+        bool all_obs = true;
+        const size_t ny = (size_t)S.n_series * T;
+        for (size_t i = 0; i < ny && all_obs; i++) all_obs = std::isfinite(S.y[i]);
+        S.dense_hint = all_obs ? 1 : 0;
+    }
     if (S.u) memcpy(pin + (S.d_u - S.d_in), S.u, sizeof(double) * nuv * T * S.p);
     if (S.v) memcpy(pin + (S.d_v - S.d_in), S.v, sizeof(double) * nuv * T * S.q);
     memcpy(pin + (S.d_th0 - S.d_in), S.theta0, sizeof(double) * (size_t)n * P);
@@ -823,7 +844,7 @@ static int slice_run(Slice &S) {
         S.shared_uv, S.off.data(), (const double *)(A->dev + S.d_th0), S.niter, S.tol, S.algo,
         (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
         (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
-        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels());
+        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint);
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
     if (S.fuse && S.trace_on_device) {
@@ -948,7 +969,7 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
             S.u ? (const double *)(A->dev + S.d_u) : nullptr, S.v ? (const double *)(A->dev + S.d_v) : nullptr,
             S.shared_uv, sel_off.data(), (const double *)(dw + W.theta0), niter, S.tol, S.algo,
             (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
-            (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb);
+            (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb, nullptr, S.dense_hint);
         if (rc) return rc;
     }
     // the winners' fit: one smoother pass at theta_w on the prepared series

@@ -160,13 +160,33 @@ def test_config2_whole_batch_converged(eng):
     per-half work queue; AUTO must have picked the pair kernel."""
     import bench
     Y, U, V, shared, off, th0, n = bench.build_problem("cfg2", "dense", 1, 0)
-    assert _plan_name(1000, 1, 2, 1e-5)[1] == "em_pair_kernel<1, 2, 32, true>"
+    assert _plan_name(1000, 1, 2, 1e-5, PAIR)[1] == "em_pair_kernel<1, 2, 32, true>"
     ref = _oracle(Y, U, V, np.zeros(n), th0, 1000, 1e-5)
     r = eng.em_batch(Y[0], U[0].T.copy(), V[0].T.copy(), th0, niter=1000, tol=1e-5)
     _check(r, ref, "cfg2")
     from oracle import oracle as O
     p = 1
     assert eng.select_restart(r["lik"], r["theta"], 1, 2) == O.select(ref[1], ref[0][:, 1 + p])
+
+
+def test_auto_choice_with_early_stopping(eng):
+    """AUTO with tol > 0: the host-pointer entries take the pair kernel only when every series is
+    fully observed (iteration counts of masked series spread too widely for two cells per wave);
+    the device entry / ldsr_em_plan cannot look at y and stay on the scan kernel."""
+    from ldsr_amd import synth
+    T, p, q = 1000, 1, 2
+    th0 = synth.make_init_packed(p, q, 24, seed=2)
+    assert _plan_name(T, p, q, 0.0)[1].startswith("em_pair_kernel")
+    assert _plan_name(T, p, q, 1e-5)[1].startswith("em_scan_kernel")
+    for mask, same_as in (("dense", PAIR), ("paleo", SCAN)):
+        y, u, v = _series(T, p, q, 4, mask)
+        a = eng.em_batch(y, u, v, th0, niter=300, tol=1e-5)
+        b = eng.em_batch(y, u, v, th0, niter=300, tol=1e-5, algo=same_as)
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["lik"], b["lik"]), mask
+        # tol == 0: the pair kernel whatever the mask
+        a = eng.em_batch(y, u, v, th0, niter=12, tol=0.0)
+        b = eng.em_batch(y, u, v, th0, niter=12, tol=0.0, algo=PAIR)
+        assert np.array_equal(a["theta"], b["theta"]), mask
 
 
 def test_large_scale_values(eng):
