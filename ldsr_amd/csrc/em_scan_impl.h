@@ -106,6 +106,20 @@ __device__ __forceinline__ void red_rounds(double *x, int lane) {
         red_rounds<NK, D / 2>(x, lane);
     }
 }
+// Butterfly all-reduce (round 1's form): N log2(64) adds, but no select / broadcast code -- kept
+// for the FIT instantiations, which run once per winner and whose register budget (they also
+// carry the fit's output pointers) the halving form's temporaries overflowed into scratch.
+template <int N>
+__device__ __forceinline__ void wave_sum_butterfly(double (&x)[N]) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        double t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = __shfl_xor(x[i], d, 64);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += t[i];
+    }
+}
 // wave-uniform totals of x[0..N) over all 64 lanes (left in x, the same in every lane)
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
@@ -900,7 +914,8 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
             for (int k = 0; k < PP; k++) { red[NB + QQ + k] = aTx1u[k]; red[NB + QQ + PP + k] = aTux[k]; }
             if (FIT) red[NR - 1] = aSsq;
-            wave_sum_n<NR>(red);
+            if constexpr (FIT) wave_sum_butterfly<NR>(red);
+            else wave_sum_n<NR>(red);
             double term0 = readlane_d(term, 0);        // Xs^2 + Vs at t = 0 (wave 0)
             S.X0 = readlane_d(Xs, 0);                  // :218  (wave 0)
             S.V0 = readlane_d(Vs, 0);                  // :219
