@@ -76,6 +76,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     int cell = c0 + (alive ? k : 0);
     Theta<PP, QQ> th;
     load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
@@ -396,6 +397,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;   // :272
         if (alive && stop) {
             // theta stays the one that produced this fit (:276-279)
+            white_out(th, (SeriesConstK)sc);
             if (vl == 0) {
                 store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
                 if (prm.liks && prm.liks_nanfill)
@@ -414,13 +416,14 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                         alive = true;
                         cell = c0 + kn;
                         load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+                        white_in(th, (SeriesConstK)sc);
                         it = 0;
                         lik = NAN; lik1 = NAN; lik2 = NAN;
                     }
                 }
             }
         } else {
-            mstep_update<PP, QQ, true>(th, S, (SeriesConstK)sc, T);
+            mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
         }
     }
 }

@@ -441,6 +441,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         return;
     }
 
+    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
     bool interrupted = false;   // the host raised the interrupt flag (src/EM.cpp:261-262 polls too)
@@ -985,11 +986,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         bool stop = it >= prm.niter || interrupted;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
-#ifdef LDSR_SC_PLAIN     // A/B switch: the round-1 form (vector loads through a plain pointer)
-        mstep_update<PP, QQ, true>(th, S, sc, T);
-#else
-        mstep_update<PP, QQ, true>(th, S, (SeriesConstK)sc, T);
-#endif
+        mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
         // theta is wave-uniform by construction; say so to the compiler (SGPR residency)
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
         th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);
@@ -1001,6 +998,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
 
     if (lane == 0 && wv == 0) {
         if constexpr (!FIT) {
+            white_out(th, (SeriesConstK)sc);
             store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
             if (prm.liks && prm.liks_nanfill)
                 for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;

@@ -59,6 +59,34 @@ __device__ static bool invert_small(double *a, double *inv, int n) {
     return true;
 }
 
+// Cholesky factor of the n x n SPD matrix `a` (stride LDSR_MAXPQ): on return `l` holds the lower
+// factor and `li` its inverse, both zero above the diagonal inside n x n and untouched
+// (identity padding) outside.  One thread.  False if a pivot is not positive.
+__device__ static bool chol_small(const double *a, double *l, double *li, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) { l[i * LDSR_MAXPQ + j] = 0.0; li[i * LDSR_MAXPQ + j] = 0.0; }
+    for (int j = 0; j < n; j++) {
+        double d = a[j * LDSR_MAXPQ + j];
+        for (int k = 0; k < j; k++) d -= l[j * LDSR_MAXPQ + k] * l[j * LDSR_MAXPQ + k];
+        if (!(d > 0.0) || !isfinite(d)) return false;
+        const double ljj = sqrt(d);
+        l[j * LDSR_MAXPQ + j] = ljj;
+        for (int i = j + 1; i < n; i++) {
+            double e = a[i * LDSR_MAXPQ + j];
+            for (int k = 0; k < j; k++) e -= l[i * LDSR_MAXPQ + k] * l[j * LDSR_MAXPQ + k];
+            l[i * LDSR_MAXPQ + j] = e / ljj;
+        }
+    }
+    for (int c = 0; c < n; c++) {            // forward substitution, column c of the inverse
+        for (int i = c; i < n; i++) {
+            double e = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; k++) e -= l[i * LDSR_MAXPQ + k] * li[k * LDSR_MAXPQ + c];
+            li[i * LDSR_MAXPQ + c] = e / l[i * LDSR_MAXPQ + i];
+        }
+    }
+    return true;
+}
+
 __device__ __forceinline__ double prep_wave_sum(double x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -101,43 +129,14 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
         }
     }
-    // chunk-transposed images (layout: em_scan_impl.h): the K = 1+PP+QQ values of a step in
-    // pairs, pair m of step j of virtual lane l at [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where
-    // missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
-    // kernel's (32 lanes, its own chunk length).
-    auto build_image = [&](double *im, int L, int NL) {
-        const int K = 1 + PP + QQ, KP = (K + 1) / 2;
-        const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
-        for (int e = tid; e < NL * L * KP * 2; e += 256) {
-            const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
-            const int i = 2 * m + h;
-            const int t = l * (L - 1) + min(l, rp) + j;
-            const bool ok = l < nl && (j < L - 1 || l < rp);
-            double val = 0.0;
-            if (ok) {
-                if (i == 0) {
-                    const double yv = y[t];
-                    val = isfinite(yv) ? yv : 0.0;
-                } else if (i <= PP) {
-                    const int k = i - 1;
-                    val = (u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
-                } else if (i < K) {
-                    const int k = i - 1 - PP;
-                    val = (v && k < q) ? v[(long)t * q + k] : 0.0;
-                }
-            }
-            im[e] = val;
-        }
-    };
-    if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL);
-    if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, 32);
     // identity / zero padding of the statistics
     for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
         const double id = ((i / LDSR_MAXPQ) == (i % LDSR_MAXPQ)) ? 1.0 : 0.0;
         sc.Svv_inv[i] = id;
         sc.Tuu_inv[i] = id;
+        sc.Lv[i] = id; sc.Lv_inv[i] = id; sc.Lu[i] = id; sc.Lu_inv[i] = id;
     }
-    if (tid < LDSR_MAXPQ) { sc.Syv[tid] = 0.0; sc.wv[tid] = 0.0; }
+    if (tid < LDSR_MAXPQ) { sc.Syv[tid] = 0.0; sc.wv[tid] = 0.0; sc.Syv_w[tid] = 0.0; }
     __syncthreads();
 
     // statistic ids: [0, q*q) Svv(k,l); [.., +p*p) Tuu(k,l); [.., +q) Syv(k); last: Syy + counts
@@ -192,9 +191,17 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     __syncthreads();
     if (tid == 0) {
         bool ok = sc.n_obs > 0;
+        // Cholesky factors of Svv / Tuu for the whitened images (before they are inverted in place)
+        if (v) ok = chol_small(sc.Svv_inv, sc.Lv, sc.Lv_inv, q) && ok;
+        if (u) ok = chol_small(sc.Tuu_inv, sc.Lu, sc.Lu_inv, p) && ok;
         if (v) ok = invert_small(sc.Svv_inv, inv_ws, q) && ok;
         if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p) && ok;
         sc.status = ok ? 0 : 2;
+        for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
+            double a = 0.0;
+            for (int ll = 0; ll <= kk; ll++) a += sc.Lv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];
+            sc.Syv_w[kk] = a;
+        }
         sc.rn_obs = 1.0 / (double)sc.n_obs;
         sc.rTm1 = 1.0 / (double)(T - 1);
         for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
@@ -204,6 +211,41 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
         }
     }
     __syncthreads();
+    if (sc.status == 0) {
+        // chunk-transposed images (layout: em_scan_impl.h) of y and the WHITENED inputs
+        // (ldsr_device.h mstep_update_white; built after the factors): the K = 1+PP+QQ values of a step in
+        // pairs, pair m of step j of virtual lane l at [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where
+        // missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
+        // kernel's (32 lanes, its own chunk length).
+        auto build_image = [&](double *im, int L, int NL) {
+            const int K = 1 + PP + QQ, KP = (K + 1) / 2;
+            const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+            for (int e = tid; e < NL * L * KP * 2; e += 256) {
+                const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
+                const int i = 2 * m + h;
+                const int t = l * (L - 1) + min(l, rp) + j;
+                const bool ok = l < nl && (j < L - 1 || l < rp);
+                double val = 0.0;
+                if (ok) {
+                    if (i == 0) {
+                        const double yv = y[t];
+                        val = isfinite(yv) ? yv : 0.0;
+                    } else if (i <= PP) {             // whitened inputs: row k of Lu^{-1} u_t / Lv^{-1} v_t
+                        const int k = i - 1;
+                        if (u && k < p && t < T - 1)
+                            for (int j = 0; j <= k; j++) val = fma(sc.Lu_inv[k * LDSR_MAXPQ + j], u[(long)t * p + j], val);
+                    } else if (i < K) {
+                        const int k = i - 1 - PP;
+                        if (v && k < q)
+                            for (int j = 0; j <= k; j++) val = fma(sc.Lv_inv[k * LDSR_MAXPQ + j], v[(long)t * q + j], val);
+                    }
+                }
+                im[e] = val;
+            }
+        };
+        if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL);
+        if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, 32);
+    }
     {   // cooperative copy of the result to global memory
         const int *src = reinterpret_cast<const int *>(&sc);
         int *dst = reinterpret_cast<int *>(prm.sc + s);

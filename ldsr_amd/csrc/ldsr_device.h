@@ -24,6 +24,12 @@ struct SeriesConst {
     double Svv_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_obs v_t v_t')^{-1}   (:161), identity padded
     double Tuu_inv[LDSR_MAXPQ * LDSR_MAXPQ];  // (sum_{t<T-1} u_t u_t')^{-1} (:193), identity padded
     double rn_obs, rTm1;                      // 1 / n_obs, 1 / (T - 1): the divisors of R (:177) and Q (:210)
+    // Whitened inputs of the scan / pair kernels (their series images hold Lv^{-1} v_t and
+    // Lu^{-1} u_t): Cholesky factors Svv = Lv Lv', Tuu = Lu Lu' (lower, identity padded), their
+    // inverses, and Lv^{-1} Syv.  See mstep_update_white().
+    double Lv[LDSR_MAXPQ * LDSR_MAXPQ], Lv_inv[LDSR_MAXPQ * LDSR_MAXPQ];
+    double Lu[LDSR_MAXPQ * LDSR_MAXPQ], Lu_inv[LDSR_MAXPQ * LDSR_MAXPQ];
+    double Syv_w[LDSR_MAXPQ];
 };
 
 template <int PP, int QQ>
@@ -188,6 +194,98 @@ __device__ __forceinline__ void mstep_update(Theta<PP, QQ> &th, const Sums<PP, Q
     th.Q = FAST ? qacc * sc->rTm1 : qacc / (double)(T - 1);
     th.mu1 = S.X0;
     th.V1 = S.V0;
+}
+
+// The same M-step in WHITENED input coordinates (scan / pair kernels).  The regression of y on
+// (x, v) and of x_{t+1} on (x_t, u_t) is invariant under an invertible change of basis of the
+// exogenous inputs: with v~_t = Lv^{-1} v_t (Svv = Lv Lv') the observed second moment of v~ is the
+// identity, D~ = D Lv gives D~ v~_t = D v_t, and the formulas above lose both matrix-vector
+// products (zv = Sxv~, Svv^{-1} Syv = Syv~): q^2 + 2 p^2 fp64 FMAs and as many scalar loads per EM
+// iteration (cfg3: 96 of each) for two q x q products per CELL (white_in at load, white_out at
+// store).  The series image is built from whitened inputs by series_prep_kernel; sums over it are
+// Sxv~, Tux~, Tx1u~ by construction.  theta inside the EM loop holds (B~, D~).
+template <int PP, int QQ, typename SCP = const SeriesConst *>
+__device__ __forceinline__ void mstep_update_white(Theta<PP, QQ> &th, const Sums<PP, QQ> &S, SCP sc, int T) {
+    double numC = S.Syx, denC = S.Sxx;
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        numC = fma(-sc->Syv_w[k], S.Sxv[k], numC);
+        denC = fma(-S.Sxv[k], S.Sxv[k], denC);
+    }
+    const double C = numC * fast_rcp(denC);
+    double racc = fma(-C, S.Syx, sc->Syy);
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        const double d = fma(-C, S.Sxv[k], sc->Syv_w[k]);
+        th.D[k] = d;
+        racc = fma(-d, sc->Syv_w[k], racc);
+    }
+    th.C = C;
+    th.R = racc * sc->rn_obs;
+    double numA = S.Tx1x, denA = S.Txx;
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        numA = fma(-S.Tx1u[k], S.Tux[k], numA);
+        denA = fma(-S.Tux[k], S.Tux[k], denA);
+    }
+    const double A = numA * fast_rcp(denA);
+    double qacc = fma(-A, S.Tx1x, S.Tx1x1);
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        const double b = fma(-A, S.Tux[k], S.Tx1u[k]);
+        th.B[k] = b;
+        qacc = fma(-b, S.Tx1u[k], qacc);
+    }
+    th.A = A;
+    th.Q = qacc * sc->rTm1;
+    th.mu1 = S.X0;
+    th.V1 = S.V0;
+}
+
+// theta (B, D) -> whitened (B~, D~) = (B Lu, D Lv), and back with the inverse factors
+template <int PP, int QQ, typename SCP>
+__device__ __forceinline__ void white_in(Theta<PP, QQ> &th, SCP sc) {
+    double d[QQ], b[PP];
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = k; j < QQ; j++) a = fma(th.D[j], sc->Lv[j * LDSR_MAXPQ + k], a);
+        d[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = k; j < PP; j++) a = fma(th.B[j], sc->Lu[j * LDSR_MAXPQ + k], a);
+        b[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < QQ; k++) th.D[k] = d[k];
+#pragma unroll
+    for (int k = 0; k < PP; k++) th.B[k] = b[k];
+}
+template <int PP, int QQ, typename SCP>
+__device__ __forceinline__ void white_out(Theta<PP, QQ> &th, SCP sc) {
+    double d[QQ], b[PP];
+#pragma unroll
+    for (int k = 0; k < QQ; k++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = k; j < QQ; j++) a = fma(th.D[j], sc->Lv_inv[j * LDSR_MAXPQ + k], a);
+        d[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = k; j < PP; j++) a = fma(th.B[j], sc->Lu_inv[j * LDSR_MAXPQ + k], a);
+        b[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < QQ; k++) th.D[k] = d[k];
+#pragma unroll
+    for (int k = 0; k < PP; k++) th.B[k] = b[k];
 }
 
 // Kernel argument block shared by the EM kernels.
