@@ -83,7 +83,9 @@ extern "C" {
 #define LDSR_ALGO_SCAN 2   /* one to four wavefronts per cell, parallel-in-time scans (T <= 8192,
                               p, q <= 8); AUTO picks it whenever it applies and PAIR does not */
 #define LDSR_ALGO_PAIR 3   /* the same scans with TWO cells per wavefront (one per 32-lane half):
-XX */
+                              513 <= T <= 1024, p, q <= 4, narrower ranges of T for the wider inputs
+                              (ldsr_em_plan tells); AUTO's first choice where it applies -- with
+                              tol > 0 only for fully observed series */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);
@@ -162,8 +164,10 @@ int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, i
                          size_t workspace_bytes);
 
 /* Which kernel a call with these arguments launches: writes its name as rocprofv3 prints it
- * (e.g. "em_scan_kernel<1, 2, 16, 1, false, false>") into buf and returns the resolved algorithm
- * (LDSR_ALGO_SERIAL / LDSR_ALGO_SCAN), or a negative value for unsupported arguments. */
+ * (e.g. "em_pair_kernel<1, 2, 32, false>") into buf and returns the resolved algorithm
+ * (LDSR_ALGO_SERIAL / LDSR_ALGO_SCAN / LDSR_ALGO_PAIR), or a negative value for unsupported arguments.
+ * With LDSR_ALGO_AUTO and tol > 0 it reports what ldsr_em_batch_device runs (the scan kernel); the
+ * host-pointer entries additionally take the pair kernel when every series is fully observed. */
 int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len);
 
 /* Batched Kalman_smoother: one E-step for each cell's theta.  Host pointers.

@@ -1,6 +1,6 @@
 """Randomized GPU-vs-oracle parity fuzz (run on the GPU box):  python tools/fuzz_parity.py [n] [seed]
 Random T (2..8192: one, two and four waves per cell), p, q (1..8, sometimes absent), NA patterns, 1..5 series with own or shared
-inputs, ragged cell counts, niter / tol; serial kernel and AUTO (= scan kernel when supported).  Prints one line per failing case and a
+inputs, ragged cell counts, niter / tol; serial kernel, AUTO, the scan kernel and (where it applies) the pair kernel.  Prints one line per failing case and a
 summary; exit status 1 if anything failed."""
 import os
 import sys
@@ -23,9 +23,11 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
     for case in range(n):
-        T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 300), rng.integers(300, 1100),
-                            rng.integers(1100, 2049), rng.integers(2049, 4097), rng.integers(4097, 8193)]))
+        T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(513, 1025),
+                            rng.integers(513, 1025), rng.integers(1100, 2049), rng.integers(2049, 4097), rng.integers(4097, 8193)]))
         p, q = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        if 513 <= T <= 1024 and rng.random() < 0.7:      # the pair kernel's shapes
+            p, q = int(rng.integers(1, 5)), int(rng.integers(1, 5))
         S = int(rng.integers(1, 6))
         shared = bool(rng.integers(0, 2)) and S > 1
         has_u, has_v = rng.random() > 0.15, rng.random() > 0.15
@@ -69,7 +71,11 @@ def main():
             return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
         ref = O.em_batch(Y, tm(U), tm(V), soc, th0, niter, tol, n_threads=8)
         ok = np.isfinite(ref[1])
-        for algo in (1, 0):     # serial, and AUTO (scan kernel whenever the series fits in LDS)
+        import ctypes
+        algos = [1, 0, 2] if T <= 8192 and max(pe, qe) <= 8 else [1, 0]
+        if ldsr_amd._lib.lib().ldsr_em_plan(T, pe, qe, max(niter, 2), tol, 3, ctypes.create_string_buffer(8), 8) == 3:
+            algos.append(3)      # two cells per wave
+        for algo in algos:     # serial, AUTO, scan kernel, pair kernel where it applies
             try:
                 r = ldsr_amd.em_batch(Y, U, V, th0, cell_offsets=off, niter=niter, tol=tol, algo=algo)
             except Exception as e:   # noqa: BLE001

@@ -39,7 +39,7 @@ def per_kernel(rows, name_part):
 
 
 def write_filtered(rows, dst):
-    keep = [r for r in rows if "em_scan" in r["Kernel_Name"] or "em_serial" in r["Kernel_Name"]
+    keep = [r for r in rows if "em_scan" in r["Kernel_Name"] or "em_pair" in r["Kernel_Name"] or "em_serial" in r["Kernel_Name"]
             or "series_prep" in r["Kernel_Name"]]
     if not keep:
         return
