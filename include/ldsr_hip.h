@@ -166,8 +166,10 @@ int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, i
 /* Which kernel a call with these arguments launches: writes its name as rocprofv3 prints it
  * (e.g. "em_pair_kernel<1, 2, 32, false>") into buf and returns the resolved algorithm
  * (LDSR_ALGO_SERIAL / LDSR_ALGO_SCAN / LDSR_ALGO_PAIR), or a negative value for unsupported arguments.
- * With LDSR_ALGO_AUTO and tol > 0 it reports what ldsr_em_batch_device runs (the scan kernel); the
- * host-pointer entries additionally take the pair kernel when every series is fully observed. */
+ * With LDSR_ALGO_AUTO it assumes a launch large enough to fill the device (below ~3600 cells the
+ * entries keep the scan kernel, whose four-cell workgroups spread over more CUs), and with tol > 0
+ * it reports what ldsr_em_batch_device runs (the scan kernel); the host-pointer entries additionally
+ * take the pair kernel when every series is fully observed. */
 int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len);
 
 /* Batched Kalman_smoother: one E-step for each cell's theta.  Host pointers.

@@ -346,6 +346,20 @@ struct Carver {
 };
 
 // ---- algorithm choice / workspace layout -------------------------------------------------------
+// compute units of a device (cached)
+static int device_cu_count(int device) {
+    static std::mutex mu;
+    static std::vector<int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= device) cache.resize((size_t)device + 1, 0);
+    if (!cache[(size_t)device]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        cache[(size_t)device] = n;
+    }
+    return cache[(size_t)device];
+}
+
 // LDSR_PAIR=0 in the environment keeps AUTO off the two-cells-per-wave kernel (same-box A/B runs)
 static bool pair_enabled() {
     static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
@@ -517,6 +531,14 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
     // series known to be fully observed (the host-pointer entries look; dense_hint).
     if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
+    // ... and only when its sixteen-cell workgroups (one per CU) fill the device: 512 cells are 32
+    // pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128 of them (a quarter of the time).
+    if (was_auto && algo == LDSR_ALGO_PAIR) {
+        const int cpbp = em_pair_cells_per_block(T, PP, QQ);
+        long wgs = 0;
+        for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + cpbp - 1) / cpbp;
+        if (wgs * 8 < 7 * (long)device_cu_count(device)) algo = LDSR_ALGO_SCAN;
+    }
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR)
         return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))

@@ -169,23 +169,30 @@ def test_config2_whole_batch_converged(eng):
     assert eng.select_restart(r["lik"], r["theta"], 1, 2) == O.select(ref[1], ref[0][:, 1 + p])
 
 
-def test_auto_choice_with_early_stopping(eng):
-    """AUTO with tol > 0: the host-pointer entries take the pair kernel only when every series is
-    fully observed (iteration counts of masked series spread too widely for two cells per wave);
-    the device entry / ldsr_em_plan cannot look at y and stay on the scan kernel."""
+def test_auto_choice(eng):
+    """AUTO takes the pair kernel only for launches whose sixteen-cell workgroups fill the device
+    (below ~3600 cells the scan kernel's four-cell workgroups spread over more CUs), and with
+    tol > 0 only when every series is fully observed (iteration counts of masked series spread too
+    widely for two cells per wave; the device entry / ldsr_em_plan cannot look at y and stay on
+    the scan kernel)."""
     from ldsr_amd import synth
     T, p, q = 1000, 1, 2
-    th0 = synth.make_init_packed(p, q, 24, seed=2)
     assert _plan_name(T, p, q, 0.0)[1].startswith("em_pair_kernel")
     assert _plan_name(T, p, q, 1e-5)[1].startswith("em_scan_kernel")
+    big = synth.make_init_packed(p, q, 4096, seed=2)
+    small = big[:24].copy()
     for mask, same_as in (("dense", PAIR), ("paleo", SCAN)):
         y, u, v = _series(T, p, q, 4, mask)
-        a = eng.em_batch(y, u, v, th0, niter=300, tol=1e-5)
-        b = eng.em_batch(y, u, v, th0, niter=300, tol=1e-5, algo=same_as)
+        a = eng.em_batch(y, u, v, big, niter=300, tol=1e-5)
+        b = eng.em_batch(y, u, v, big, niter=300, tol=1e-5, algo=same_as)
         assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["lik"], b["lik"]), mask
-        # tol == 0: the pair kernel whatever the mask
-        a = eng.em_batch(y, u, v, th0, niter=12, tol=0.0)
-        b = eng.em_batch(y, u, v, th0, niter=12, tol=0.0, algo=PAIR)
+        # tol == 0: the pair kernel whatever the mask ...
+        a = eng.em_batch(y, u, v, big, niter=12, tol=0.0)
+        b = eng.em_batch(y, u, v, big, niter=12, tol=0.0, algo=PAIR)
+        assert np.array_equal(a["theta"], b["theta"]), mask
+        # ... unless the launch is small
+        a = eng.em_batch(y, u, v, small, niter=12, tol=0.0)
+        b = eng.em_batch(y, u, v, small, niter=12, tol=0.0, algo=SCAN)
         assert np.array_equal(a["theta"], b["theta"]), mask
 
 
