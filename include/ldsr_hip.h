@@ -83,7 +83,7 @@ extern "C" {
 #define LDSR_ALGO_SCAN 2   /* one to four wavefronts per cell, parallel-in-time scans (T <= 8192,
                               p, q <= 8); AUTO picks it whenever it applies and PAIR does not */
 #define LDSR_ALGO_PAIR 3   /* the same scans with TWO cells per wavefront (one per 32-lane half):
-                              513 <= T <= 1024, p, q <= 4, narrower ranges of T for the wider inputs
+                              65 <= T <= 1024, p, q <= 4, narrower ranges of T for the wider inputs
                               (ldsr_em_plan tells); AUTO's first choice where it applies -- with
                               tol > 0 only for fully observed series */
 

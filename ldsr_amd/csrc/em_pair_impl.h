@@ -1,5 +1,5 @@
-// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of 513 to
-// 1024 steps with narrow inputs (T <= 32 L, 17 <= L <= 32, padded p, q <= 4; kernels_scan.hip
+// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of 65 to
+// 1024 steps with narrow inputs (T <= 32 L, 3 <= L <= 32, padded p, q <= 4; kernels_scan.hip
 // pair_plan() has the exact ranges).
 //
 // Why.  In em_scan_kernel (one cell per 64-lane wave, em_scan_impl.h) half of the ~1500 VALU

@@ -100,9 +100,9 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 // count) it is 20-25 % SLOWER than the one-cell-per-wave kernel, with 8 it is 10-15 % faster.
 PairPlan pair_plan(int T, int PP, int QQ) {
     PairPlan p;
-    if (PP > 4 || QQ > 4 || T <= 512) return p;
-    // every chunk length from 17 (T = 513) to 32 (T = 1024): the shortest one wastes no lanes
-    for (int L = 17; L <= 32; L++)
+    if (PP > 4 || QQ > 4 || T <= 64) return p;
+    // every chunk length from 3 (T = 65) to 32 (T = 1024): the shortest one wastes no lanes
+    for (int L = 3; L <= 32; L++)
         if (T <= 32 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
     if (!p.L) return p;
     const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ) * sizeof(double);
@@ -130,6 +130,20 @@ hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int n_blocks, boo
     const PairPlan p = pair_plan(prm.T, PP, QQ);
     if (!p.ok || !prm.img2) return hipErrorInvalidValue;
     switch (p.L) {
+        case 3: return launch_em_pair_L<3>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 4: return launch_em_pair_L<4>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 5: return launch_em_pair_L<5>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 6: return launch_em_pair_L<6>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 7: return launch_em_pair_L<7>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 8: return launch_em_pair_L<8>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 9: return launch_em_pair_L<9>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 10: return launch_em_pair_L<10>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 11: return launch_em_pair_L<11>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 12: return launch_em_pair_L<12>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 13: return launch_em_pair_L<13>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 14: return launch_em_pair_L<14>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 15: return launch_em_pair_L<15>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 16: return launch_em_pair_L<16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 17: return launch_em_pair_L<17>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 18: return launch_em_pair_L<18>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 19: return launch_em_pair_L<19>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);

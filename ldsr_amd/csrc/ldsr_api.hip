@@ -544,7 +544,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
     if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ))
-        return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 513 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
+        return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
     const int cpb = cells_per_block(algo, T, PP, QQ);
     const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                                  cells_per_block(algo_layout, T, PP, QQ));

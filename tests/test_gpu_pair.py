@@ -1,6 +1,6 @@
 """GPU parity of the two-cells-per-wave kernel (LDSR_ALGO_PAIR, em_pair_impl.h) against the CPU
 oracle: the bar of SURVEY.md Appendix B -- identical n_iter per cell, then theta and lik within
-|d| <= 1e-6 |ref| + 1e-9 -- on every chunk length it is compiled for (T = 513 .. 1024), dense and
+|d| <= 1e-6 |ref| + 1e-9 -- on every chunk length it is compiled for (T = 65 .. 1024), dense and
 masked series, both schedules (static pairs at tol = 0, per-half work queue at tol > 0), ragged
 grids (odd cell counts, one-cell series, empty series), plus the plan (AUTO picks it where it
 applies) and its error behaviour.  Follows /root/reference/tests/testthat/test-LDS-EM.R's way of
@@ -61,8 +61,9 @@ def _plan_name(T, p, q, tol, algo=0):
 
 
 # T values: both ends of every third chunk length's range, the BASELINE shapes (1000, 813), and
-# the limits of the kernel (513, 1024)
-@pytest.mark.parametrize("T", [513, 544, 545, 600, 640, 641, 700, 768, 769, 813, 832, 833, 900,
+# the limits of the kernel (65, 1024)
+@pytest.mark.parametrize("T", [65, 66, 96, 97, 128, 150, 160, 200, 224, 256, 257, 300, 352, 400, 448, 500, 512,
+                               513, 544, 545, 600, 640, 641, 700, 768, 769, 813, 832, 833, 900,
                                960, 961, 992, 993, 1000, 1023, 1024])
 @pytest.mark.parametrize("mask", ["dense", "paleo"])
 def test_every_chunk_length_matches_oracle(eng, T, mask):
@@ -220,7 +221,7 @@ def test_singular_series_and_bad_shapes(eng):
         assert np.all(r["status"] == 2) and np.all(np.isnan(r["theta"])) and np.all(r["n_iter"] == 0)
         assert np.all(np.isnan(r["liks"]))
     # shapes outside the kernel: explicit PAIR is an error, AUTO goes elsewhere
-    for (T2, p2, q2) in ((512, 1, 2), (1025, 1, 2), (1000, 5, 2), (1000, 1, 5), (1000, 1, 4), (900, 4, 4)):
+    for (T2, p2, q2) in ((64, 1, 2), (1025, 1, 2), (1000, 5, 2), (1000, 1, 5), (1000, 1, 4), (900, 4, 4)):
         assert _plan_name(T2, p2, q2, 0.0, PAIR)[0] == -1
         a, name = _plan_name(T2, p2, q2, 0.0, 0)
         assert a in (1, 2) and "em_pair" not in name

@@ -44,7 +44,7 @@ def run(T, p, q, n, niter, tol, mask, seed=5):
 
 if __name__ == "__main__":
     allok = True
-    for (T, p, q) in ((1000, 1, 2), (813, 1, 3), (864, 2, 4), (992, 1, 1), (650, 2, 2), (832, 1, 2), (800, 3, 3)):
+    for (T, p, q) in ((1000, 1, 2), (813, 1, 3), (864, 2, 4), (992, 1, 1), (650, 2, 2), (832, 1, 2), (800, 3, 3), (257, 1, 2), (300, 2, 2), (400, 1, 4), (512, 4, 4), (65, 1, 1), (96, 1, 2), (100, 2, 4), (200, 3, 3), (256, 1, 2)):
         for mask in ("dense", "paleo", "holes"):
             allok &= run(T, p, q, 37, 40, 0.0, mask)
             allok &= run(T, p, q, 101, 300, 1e-5, mask)
