@@ -86,6 +86,8 @@ extern "C" {
                               65 <= T <= 1024, p, q <= 4, narrower ranges of T for the wider inputs
                               (ldsr_em_plan tells); AUTO's first choice where it applies -- with
                               tol > 0 only for fully observed series */
+#define LDSR_ALGO_QUAD 4   /* FOUR cells per wavefront (one per 16-lane DPP row): 65 <= T <= 512,
+                              p, q <= 4; AUTO's first choice there for launches that fill the device */
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);

@@ -27,7 +27,7 @@ from .synth import make_init_packed
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
-ALGO_AUTO, ALGO_SERIAL, ALGO_SCAN, ALGO_PAIR = 0, 1, 2, 3
+ALGO_AUTO, ALGO_SERIAL, ALGO_SCAN, ALGO_PAIR, ALGO_QUAD = 0, 1, 2, 3, 4
 
 
 def _d(a):

@@ -27,8 +27,10 @@
 #pragma once
 #include "em_scan_impl.h"
 
-__host__ __device__ constexpr long pair_image_doubles(int L, int PP, int QQ) {
-    return (long)32 * L * 2 * scan_pairs(PP, QQ);
+// lanes per cell LPC = 32 (two cells per wave, T <= 1024) or 16 (FOUR cells per wave, one per DPP
+// row, T <= 512): the series image has LPC virtual lanes
+__host__ __device__ constexpr long pair_image_doubles(int L, int PP, int QQ, int LPC = 32) {
+    return (long)LPC * L * 2 * scan_pairs(PP, QQ);
 }
 // LDS strip of one wave: h_t of steps 0 .. L-2 for 64 lanes (the predicated step L-1 keeps its
 // h in a register)
@@ -36,12 +38,15 @@ __host__ __device__ constexpr long pair_strip_doubles(int L) { return (long)64 *
 
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
-template <int PP, int QQ, int L, bool DENSE, bool QUEUE>
+template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
                                              int s, int c0, int nc, int lane, int wave) {
     constexpr int KP = scan_pairs(PP, QQ);
-    const int half = lane >> 5, vl = lane & 31, hbase = lane & 32;
-    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * 32 + vl) * 2 + (i & 1)]; };
+    static_assert(LPC == 32 || LPC == 16, "two or four cells per wave");
+    constexpr int CPW = 64 / LPC;                         // cells per wave
+    // `half` = which cell of the wave this lane works for (the name dates from LPC = 32)
+    const int half = lane / LPC, vl = lane & (LPC - 1), hbase = lane & ~(LPC - 1);
+    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
     auto Yat = [&](int j) { return val(j, 0); };
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
@@ -67,7 +72,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     }
 
     // this half's cell
-    int k = QUEUE ? 0 : 2 * wave + half;
+    int k = QUEUE ? 0 : CPW * wave + half;
     if constexpr (QUEUE) {
         if (vl == 0) k = atomicAdd(prm.queue + s, 1);
         k = __shfl(k, hbase, 64);
@@ -190,7 +195,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
         prenorm(M);
         M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
-        M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+        if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
         // exit state of this lane's chunk, then the entry state = exit state of the lane before
         // (lane 0 of each half: the cell's initial state)
         const double n_in = th.V1, d_in = 1.0, x_in = th.mu1;
@@ -280,7 +285,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         }
         RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
 #undef RSCAN_ROUND
-        {
+        if constexpr (LPC == 32) {
             // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
             const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
             const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
@@ -294,7 +299,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         // chunk is the next lane's, and the zero terminal value for the half's last lane
         double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
         double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
-        if (vl == 31) { Xn = 0.0; Vn = 0.0; }
+        if (vl == LPC - 1) { Xn = 0.0; Vn = 0.0; }
 
         // ------------------------------------------------ B2: serial reverse re-run + M-step sums
         // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
@@ -355,6 +360,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);
             constexpr int NR = NB + QQ + 2 * PP;
+            static_assert(NR <= 2 * LPC, "reduction gather handles two slots per lane");
             double red[NR];
             red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
             if (!DENSE) red[5] = aSxx;
@@ -364,17 +370,20 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = aTx1u[p_]; red[NB + QQ + PP + p_] = aTux[p_]; }
             // recursive halving over the half's 32 lanes (em_scan_impl.h), then every lane fetches
             // the totals from their home lanes of its own half
-            red_rounds<NR, 16>(red, lane);
+            red_rounds<NR, LPC / 2>(red, lane);
             {
-                const double t0 = red[0];
+                // (more values than lanes -- 17 or 18 sums on the 16 lanes of a quad cell -- leave two
+                // live slots per lane)
+                const double t0 = red[0], t1 = red[1];
 #pragma unroll
-                for (int i = 0; i < NR; i++) red[i] = shfl_d(t0, hbase | red_home(i, NR, 32));
+                for (int i = 0; i < NR; i++)
+                    red[i] = shfl_d(red_slot(i, NR, LPC) == 0 ? t0 : t1, hbase | red_home(i, NR, LPC));
             }
             S.X0 = shfl_d(Xn, hbase);                // :218
             S.V0 = shfl_d(Vn, hbase);                // :219
             const double term0 = fma(S.X0, S.X0, S.V0);
             const unsigned long long negm = __ballot(sneg < 0);
-            const bool neg = ((negm >> hbase) & 0xffffffffull) != 0;   // log of a negative Sigma
+            const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
             S.Syx = red[0]; S.Tx1x = red[1];
             S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
@@ -431,10 +440,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 // One workgroup = up to 8 waves = up to 16 cells of ONE series.  Static: wave w owns cells
 // c0 + 2w, c0 + 2w + 1 of the block (nc of them).  QUEUE: (c0, nc) is the series' whole range and
 // every half pulls cells from the per-series counter.
-template <int PP, int QQ, int L, bool QUEUE>
+template <int PP, int QQ, int L, int LPC, bool QUEUE>
 __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr long IMG = pair_image_doubles(L, PP, QQ);
+    constexpr long IMG = pair_image_doubles(L, PP, QQ, LPC);
     const int b = blockIdx.x;
     const int s = prm.blk_series[b];
     const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
@@ -458,20 +467,21 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
         }
         return;
     }
-    if (!QUEUE && 2 * wave >= nc) return;    // whole wave leaves; no barrier follows
+    if (!QUEUE && (64 / LPC) * wave >= nc) return;    // whole wave leaves; no barrier follows
     double *hs = smem + IMG + (long)wave * pair_strip_doubles(L) + lane;
     const bool dense = sc->n_obs == prm.T;
-    if (dense) em_pair_body<PP, QQ, L, true, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
-    else em_pair_body<PP, QQ, L, false, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
+    if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
+    else em_pair_body<PP, QQ, L, LPC, false, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
 }
 
 struct PairPlan {
     int L = 0;
-    int wpb = 0;        // waves per workgroup (2 cells each)
+    int lpc = 0;        // lanes per cell: 32 (two cells per wave) or 16 (four)
+    int wpb = 0;        // waves per workgroup
     bool ok = false;
 };
-PairPlan pair_plan(int T, int PP, int QQ);
+PairPlan pair_plan(int T, int PP, int QQ, int lpc);
 
-template <int L>
+template <int L, int LPC>
 hipError_t launch_em_pair_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,
                             hipStream_t stream);

@@ -1,0 +1,3 @@
+#define PAIR_L 6
+#define PAIR_LPC 16
+#include "em_pair_launch.inc"

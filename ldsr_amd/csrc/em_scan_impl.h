@@ -87,6 +87,15 @@ __host__ __device__ constexpr int red_home(int v, int n, int width) {
     }
     return lane;
 }
+// ... and the slot it ends in (0 unless there are more values than lanes in the group)
+__host__ __device__ constexpr int red_slot(int v, int n, int width) {
+    for (int d = width / 2; d >= 1; d >>= 1) {
+        const int nk = (n + 1) / 2;
+        if (v >= nk) v -= nk;
+        n = nk;
+    }
+    return v;
+}
 template <int N, int D>
 __device__ __forceinline__ void red_rounds(double *x, int lane) {
     if constexpr (D >= 1) {

@@ -92,20 +92,26 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 #undef CASE_LW
 }
 
-// ---- two cells per wave (em_pair_impl.h) -------------------------------------------------------
-// Smallest chunk length with L (L-1) <= T <= 32 L.  The kernel pays off only with two waves per
-// SIMD: eight waves per workgroup (one workgroup fills a CU's LDS), i.e. the 32-lane series image
-// and eight strips must fit 160 KiB -- (1,2): every L; (1,4): L <= 29; (2,4), (4,2): L <= 27;
-// (4,4): L <= 25.  Same-box A/B at 8192 cells: with 7 or 6 waves per CU (and the coarser workgroup
-// count) it is 20-25 % SLOWER than the one-cell-per-wave kernel, with 8 it is 10-15 % faster.
-PairPlan pair_plan(int T, int PP, int QQ) {
+// ---- two / four cells per wave (em_pair_impl.h) --------------------------------------------------
+// lpc = lanes per cell: 32 (two cells per wave, T <= 1024) or 16 (four, T <= 512).
+// Smallest chunk length with L (L-1) <= T <= lpc L.  The kernel pays off only with two waves per
+// SIMD: eight waves per workgroup (one workgroup fills a CU's LDS), i.e. the lpc-lane series image
+// and eight strips must fit 160 KiB -- at lpc = 32: (1,2): every L; (1,4): L <= 29; (2,4), (4,2):
+// L <= 27; (4,4): L <= 25.  Same-box A/B at 8192 cells: with 7 or 6 waves per CU (and the coarser
+// workgroup count) it is 20-25 % SLOWER than the one-cell-per-wave kernel, with 8 it is 10-15 % faster.
+PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
     PairPlan p;
-    if (PP > 4 || QQ > 4 || T <= 64) return p;
-    // every chunk length from 3 (T = 65) to 32 (T = 1024): the shortest one wastes no lanes
-    for (int L = 3; L <= 32; L++)
-        if (T <= 32 * L) { p.L = (T >= L * (L - 1)) ? L : 0; break; }
+    p.lpc = lpc;
+    if ((lpc != 32 && lpc != 16) || PP > 4 || QQ > 4 || T <= 64) return p;
+    // every chunk length from 3 to 32: the shortest one wastes no lanes (four cells per wave: from 5)
+    // (lanes 0 .. rp-1 own L steps, the others L-1: needs 1 <= rp <= nl)
+    for (int L = (lpc == 16 ? 5 : 3); L <= 32; L++) {
+        if (T > lpc * L) continue;
+        const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+        if (rp >= 1 && rp <= nl) { p.L = L; break; }
+    }
     if (!p.L) return p;
-    const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ) * sizeof(double);
+    const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ, lpc) * sizeof(double);
     const size_t strip = (size_t)pair_strip_doubles(p.L) * sizeof(double);
     if (img + 8 * strip > kLdsBytes) return p;
     p.wpb = 8;
@@ -113,53 +119,31 @@ PairPlan pair_plan(int T, int PP, int QQ) {
     return p;
 }
 
-bool em_pair_supported(int T, int PP, int QQ) { return pair_plan(T, PP, QQ).ok; }
-int em_pair_cells_per_block(int T, int PP, int QQ) { return 2 * pair_plan(T, PP, QQ).wpb; }
-void em_pair_layout(int T, int PP, int QQ, int *L, long *img_doubles) {
-    const PairPlan p = pair_plan(T, PP, QQ);
+bool em_pair_supported(int T, int PP, int QQ, int lpc) { return pair_plan(T, PP, QQ, lpc).ok; }
+int em_pair_cells_per_block(int T, int PP, int QQ, int lpc) { return (64 / lpc) * pair_plan(T, PP, QQ, lpc).wpb; }
+void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles) {
+    const PairPlan p = pair_plan(T, PP, QQ, lpc);
     *L = p.L;
-    *img_doubles = p.ok ? pair_image_doubles(p.L, PP, QQ) : 0;
+    *img_doubles = p.ok ? pair_image_doubles(p.L, PP, QQ, lpc) : 0;
 }
-void em_pair_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len) {
-    const PairPlan p = pair_plan(T, PP, QQ);
-    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %s>", PP, QQ, p.L, queue ? "true" : "false");
+void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len) {
+    const PairPlan p = pair_plan(T, PP, QQ, lpc);
+    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s>", PP, QQ, p.L, lpc, queue ? "true" : "false");
 }
 
-hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue,
+hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,
                           hipStream_t stream) {
-    const PairPlan p = pair_plan(prm.T, PP, QQ);
+    const PairPlan p = pair_plan(prm.T, PP, QQ, lpc);
     if (!p.ok || !prm.img2) return hipErrorInvalidValue;
+#define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \
+                                             : launch_em_pair_L<Lv, 16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
     switch (p.L) {
-        case 3: return launch_em_pair_L<3>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 4: return launch_em_pair_L<4>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 5: return launch_em_pair_L<5>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 6: return launch_em_pair_L<6>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 7: return launch_em_pair_L<7>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 8: return launch_em_pair_L<8>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 9: return launch_em_pair_L<9>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 10: return launch_em_pair_L<10>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 11: return launch_em_pair_L<11>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 12: return launch_em_pair_L<12>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 13: return launch_em_pair_L<13>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 14: return launch_em_pair_L<14>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 15: return launch_em_pair_L<15>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 16: return launch_em_pair_L<16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 17: return launch_em_pair_L<17>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 18: return launch_em_pair_L<18>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 19: return launch_em_pair_L<19>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 20: return launch_em_pair_L<20>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 21: return launch_em_pair_L<21>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 22: return launch_em_pair_L<22>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 23: return launch_em_pair_L<23>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 24: return launch_em_pair_L<24>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 25: return launch_em_pair_L<25>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 26: return launch_em_pair_L<26>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 27: return launch_em_pair_L<27>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 28: return launch_em_pair_L<28>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 29: return launch_em_pair_L<29>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 30: return launch_em_pair_L<30>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 31: return launch_em_pair_L<31>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-        case 32: return launch_em_pair_L<32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 3: return launch_em_pair_L<3, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        case 4: return launch_em_pair_L<4, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
+        CASE_L(5) CASE_L(6) CASE_L(7) CASE_L(8) CASE_L(9) CASE_L(10) CASE_L(11) CASE_L(12) CASE_L(13) CASE_L(14)
+        CASE_L(15) CASE_L(16) CASE_L(17) CASE_L(18) CASE_L(19) CASE_L(20) CASE_L(21) CASE_L(22) CASE_L(23)
+        CASE_L(24) CASE_L(25) CASE_L(26) CASE_L(27) CASE_L(28) CASE_L(29) CASE_L(30) CASE_L(31) CASE_L(32)
         default: return hipErrorInvalidValue;
     }
+#undef CASE_L
 }

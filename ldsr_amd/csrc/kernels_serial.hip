@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
             }
         };
         if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL);
-        if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, 32);
+        if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, prm.NL2);
     }
     {   // cooperative copy of the result to global memory
         const int *src = reinterpret_cast<const int *>(&sc);

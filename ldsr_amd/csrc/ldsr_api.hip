@@ -366,18 +366,26 @@ static bool pair_enabled() {
     return on;
 }
 
+// AUTO resolves to LDSR_ALGO_PAIR as the name of the several-cells-per-wave family (two or four
+// cells per wave); which member -- or the scan kernel after all -- runs is decided per launch
+// (em_batch_device_impl: launch size, tol, fully observed or not).
 static int resolve_algo(int algo, int T, int PP, int QQ) {
     if (algo == LDSR_ALGO_AUTO) {
-        if (pair_enabled() && em_pair_supported(T, PP, QQ)) return LDSR_ALGO_PAIR;
+        if (pair_enabled() && (em_pair_supported(T, PP, QQ, 32) || em_pair_supported(T, PP, QQ, 16)))
+            return LDSR_ALGO_PAIR;
         return em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
     }
     return algo;
 }
 
 // cells per workgroup of the EM launch (the workspace's block table is sized for the scan
-// kernel's value, the smallest of the three, whenever its image is built)
-static int cells_per_block(int algo, int T, int PP, int QQ) {
-    if (algo == LDSR_ALGO_PAIR) return em_pair_cells_per_block(T, PP, QQ);
+// kernel's value, the smallest of them, whenever its image is built)
+static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32) {
+    if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
+        if (algo == LDSR_ALGO_QUAD) lpc = 16;
+        const int c = em_pair_cells_per_block(T, PP, QQ, lpc);
+        return c > 0 ? c : 16;
+    }
     return algo == LDSR_ALGO_SCAN ? em_scan_cells_per_block(T, PP, QQ) : 64;
 }
 
@@ -385,7 +393,7 @@ struct WsLayout {
     size_t sc, yp, yz, up, vp, img, img2, blk, soc, queue, scratch, total;
     long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
     long img2_stride;                  // pair kernel's image (0 = none)
-    int max_blocks, img_L, img_NL, img2_L;
+    int max_blocks, img_L, img_NL, img2_L, img2_NL = 32;
 };
 
 static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, int n_cells,
@@ -403,7 +411,14 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     em_scan_layout(T, PP, QQ, &L.img_L, &L.img_NL, &L.img_stride);
     L.img = o; o = align256(o + sizeof(double) * (size_t)L.img_stride * n_series);
     L.img2_stride = 0; L.img2_L = 0;
-    if (algo == LDSR_ALGO_PAIR) em_pair_layout(T, PP, QQ, &L.img2_L, &L.img2_stride);
+    if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {      // room for either member's image
+        int l32 = 0, l16 = 0;
+        long s32 = 0, s16 = 0;
+        em_pair_layout(T, PP, QQ, 32, &l32, &s32);
+        em_pair_layout(T, PP, QQ, 16, &l16, &s16);
+        L.img2_stride = std::max(s32, s16);
+        L.img2_L = s32 ? l32 : l16;
+    }
     L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
     L.max_blocks = n_cells / cpb + n_series + 1;
@@ -443,9 +458,11 @@ extern "C" size_t ldsr_em_workspace_bytes(int n_series, int T, int p, int q, int
     if (n_series < 1 || T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || n_cells < 0)
         return 0;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    const int algo_in = algo;
     algo = resolve_algo(algo, T, PP, QQ);
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ)) return 0;
-    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ)) return 0;
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ, 32) && !(algo_in == LDSR_ALGO_AUTO && em_pair_supported(T, PP, QQ, 16))) return 0;
+    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(T, PP, QQ, 16)) return 0;
     // the layout for shared_uv = 0 is an upper bound for shared_uv = 1
     return ws_layout(n_series, T, PP, QQ, 0, n_cells, algo, cells_per_block(algo, T, PP, QQ)).total;
 }
@@ -468,9 +485,12 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
         if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
-    } else if (algo == LDSR_ALGO_PAIR) {
-        if (!em_pair_supported(T, PP, QQ)) return -1;
-        if (buf && len) em_pair_kernel_name(T, PP, QQ, tol > 0.0, buf, len);
+    } else if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
+        // AUTO (a launch that fills the device assumed): four cells per wave where they fit, else two
+        int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
+        if (was_auto && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+        if (!em_pair_supported(T, PP, QQ, lpc)) return -1;
+        if (buf && len) em_pair_kernel_name(T, PP, QQ, lpc, tol > 0.0, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
         if (buf && len) em_serial_kernel_name(T, PP, QQ, buf, len);
     } else {
@@ -499,6 +519,7 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.img2 = L.img2_stride ? (double *)(ws + L.img2) : nullptr;
     pp.img2_stride = L.img2_stride;
     pp.L2 = L.img2_L;
+    pp.NL2 = L.img2_NL;
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -531,23 +552,41 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
     // series known to be fully observed (the host-pointer entries look; dense_hint).
     if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
-    // ... and only when its sixteen-cell workgroups (one per CU) fill the device: 512 cells are 32
-    // pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128 of them (a quarter of the time).
+    // ... and only when its workgroups (one per CU: 16 cells at two cells per wave, 32 at four) fill
+    // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
+    // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
+    int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
     if (was_auto && algo == LDSR_ALGO_PAIR) {
-        const int cpbp = em_pair_cells_per_block(T, PP, QQ);
-        long wgs = 0;
-        for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + cpbp - 1) / cpbp;
-        if (wgs * 8 < 7 * (long)device_cu_count(device)) algo = LDSR_ALGO_SCAN;
+        auto fills = [&](int lp) {
+            if (!em_pair_supported(T, PP, QQ, lp)) return false;
+            const int c = em_pair_cells_per_block(T, PP, QQ, lp);
+            long wgs = 0;
+            for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
+            return wgs * 8 >= 7 * (long)device_cu_count(device);
+        };
+        if (fills(16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+        else if (fills(32)) lpc = 32;
+        else algo = LDSR_ALGO_SCAN;
     }
-    if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR)
+    if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR && algo != LDSR_ALGO_QUAD)
         return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
-    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ))
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ, 32))
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
-    const int cpb = cells_per_block(algo, T, PP, QQ);
-    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
-                                 cells_per_block(algo_layout, T, PP, QQ));
+    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(T, PP, QQ, 16))
+        return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
+    const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;      // several cells per wave
+    const int cpb = cells_per_block(algo, T, PP, QQ, lpc);
+    WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
+                           cells_per_block(algo_layout, T, PP, QQ));
+    if (cpw) {       // the image of the member that runs (the room is the larger of the two)
+        long sz = 0;
+        em_pair_layout(T, PP, QQ, lpc, &L.img2_L, &sz);
+        L.img2_NL = lpc;
+    } else {
+        L.img2_stride = 0;       // no pair-family launch: series_prep skips the second image
+    }
     if (workspace_bytes < L.total)
         return fail(LDSR_EINVAL, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (((size_t)d_workspace & 255) != 0) return fail(LDSR_EINVAL, "workspace must be 256-byte aligned");
@@ -563,7 +602,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
     // converges early takes the next one instead of idling.
     const bool use_queue = (algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol)) ||
-                           (algo == LDSR_ALGO_PAIR && tol > 0.0);
+                           (cpw && tol > 0.0);
     std::vector<int> bs, bc, bn;
     for (int s = 0; s < n_series; s++)
         for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
@@ -617,8 +656,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.scratch_stride = L.scratch_stride;
     int slot;
     HIPCHK(prof_begin(device, stream, &slot));
-    if (algo == LDSR_ALGO_PAIR)
-        HIPCHK(launch_em_pair(prm, PP, QQ, n_blocks, use_queue, stream));
+    if (cpw)
+        HIPCHK(launch_em_pair(prm, PP, QQ, lpc, n_blocks, use_queue, stream));
     else if (algo == LDSR_ALGO_SCAN)
         HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
     else

@@ -12,9 +12,9 @@ struct PrepParams {
     double *img;              // scan kernel: chunk-transposed series images [n_series][img_stride], or null
     long img_stride;          // doubles per image
     int L, NL;                // chunk length and virtual lanes (64 W) of the image layout
-    double *img2;             // pair kernel: second image per series (32 virtual lanes, chunk length L2), or null
+    double *img2;             // pair kernel: second image per series (NL2 virtual lanes, chunk length L2), or null
     long img2_stride;
-    int L2;
+    int L2, NL2;
     SeriesConst *sc;
     int *queue;               // [n_series] work-queue heads, reset to 0 here
 };
@@ -71,12 +71,12 @@ bool em_scan_global_image(int T, int PP, int QQ);   // series image too large fo
 bool em_scan_queue_only(int T, int PP, int QQ);     // shapes compiled with the work-queue schedule only
 bool em_scan_supported(int T, int PP, int QQ);
 int em_scan_cells_per_block(int T, int PP, int QQ);
-// two cells per wave (em_pair_impl.h): T <= 1024, padded p <= 2, q <= 4, chunk lengths compiled in
-bool em_pair_supported(int T, int PP, int QQ);
-int em_pair_cells_per_block(int T, int PP, int QQ);
-void em_pair_layout(int T, int PP, int QQ, int *L, long *img_doubles);
-hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue, hipStream_t stream);
-void em_pair_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len);
+// two (lpc = 32) or four (lpc = 16) cells per wave (em_pair_impl.h): T <= lpc * 32, padded p, q <= 4
+bool em_pair_supported(int T, int PP, int QQ, int lpc);
+int em_pair_cells_per_block(int T, int PP, int QQ, int lpc);
+void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles);
+hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue, hipStream_t stream);
+void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);

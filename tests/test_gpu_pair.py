@@ -15,7 +15,7 @@ from conftest import parity_close
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-6, 1e-9
-PAIR, SCAN = 3, 2
+PAIR, SCAN, QUAD = 3, 2, 4      # LDSR_ALGO_PAIR (two cells per wave), _SCAN, _QUAD (four cells per wave)
 
 
 @pytest.fixture(scope="module")
@@ -71,11 +71,15 @@ def test_every_chunk_length_matches_oracle(eng, T, mask):
     p, q = 1, 2
     y, u, v = _series(T, p, q, 100 + T, mask)
     th0 = synth.make_init_packed(p, q, 21, seed=T)          # odd count: one half-wave idles
-    assert _plan_name(T, p, q, 0.0)[1].startswith("em_pair_kernel<1, 2, %d, false>" % -(-T // 32))
+    # AUTO's plan (a launch that fills the device assumed): four cells per wave up to T = 512, two above
+    assert _plan_name(T, p, q, 0.0)[1] == "em_pair_kernel<1, 2, %d, %d, false>" % (
+        (max(5, -(-T // 16)), 16) if T <= 512 else (-(-T // 32), 32))
+    assert _plan_name(T, p, q, 0.0, PAIR)[1] == "em_pair_kernel<1, 2, %d, 32, false>" % max(3, -(-T // 32))
     for niter, tol in ((25, 0.0), (300, 1e-5)):
         ref = _oracle(y, u.T[None], v.T[None], np.zeros(21), th0, niter, tol)
-        r = eng.em_batch(y, u, v, th0, niter=niter, tol=tol, algo=PAIR)
-        _check(r, ref, "T=%d %s tol=%g" % (T, mask, tol))
+        for algo in (PAIR, QUAD) if T <= 512 else (PAIR,):
+            r = eng.em_batch(y, u, v, th0, niter=niter, tol=tol, algo=algo)
+            _check(r, ref, "T=%d %s tol=%g algo=%d" % (T, mask, tol, algo))
 
 
 @pytest.mark.parametrize("p,q", [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4),
@@ -95,6 +99,12 @@ def test_every_compiled_width(eng, p, q, mask):
     r2 = eng.em_batch(y, u, v, th0, niter=400, tol=1e-5, algo=SCAN)
     assert np.array_equal(r["n_iter"], r2["n_iter"])
     assert parity_close(r["theta"], r2["theta"], 1e-9, 1e-12)
+    # four cells per wave on the first 300 steps of the same series (odd cell count: idle rows)
+    ys, us, vs = y[:300].copy(), u[:, :300].copy(), v[:, :300].copy()
+    ys[0] = y[0] if np.isfinite(y[0]) else 0.1
+    ref4 = _oracle(ys, us.T[None], vs.T[None], np.zeros(45), th0[:45], 200, 1e-5)
+    r4 = eng.em_batch(ys, us, vs, th0[:45], niter=200, tol=1e-5, algo=QUAD)
+    _check(r4, ref4, "quad p=%d q=%d %s" % (p, q, mask))
 
 
 def test_absent_inputs(eng):
@@ -154,6 +164,12 @@ def test_cells_do_not_depend_on_their_partner_or_on_the_cut(eng):
         assert np.array_equal(a["theta"][7], c["theta"][0]) and a["lik"][7] == c["lik"][0]
         d = eng.em_batch(y, u, v, th0, niter=80, tol=tol, algo=PAIR, devices=[0, 0, 0])
         assert np.array_equal(a["theta"], d["theta"]) and np.array_equal(a["lik"], d["lik"])
+        # the same for four cells per wave (first 400 steps)
+        a = eng.em_batch(y[:400], u[:, :400], v[:, :400], th0, niter=80, tol=tol, algo=QUAD)
+        b = eng.em_batch(y[:400], u[:, :400], v[:, :400], th0[::-1].copy(), niter=80, tol=tol, algo=QUAD)
+        assert np.array_equal(a["theta"], b["theta"][::-1]) and np.array_equal(a["n_iter"], b["n_iter"][::-1])
+        c = eng.em_batch(y[:400], u[:, :400], v[:, :400], th0[5:6].copy(), niter=80, tol=tol, algo=QUAD)
+        assert np.array_equal(a["theta"][5], c["theta"][0]) and a["lik"][5] == c["lik"][0]
 
 
 def test_config2_whole_batch_converged(eng):
@@ -161,7 +177,7 @@ def test_config2_whole_batch_converged(eng):
     per-half work queue; AUTO must have picked the pair kernel."""
     import bench
     Y, U, V, shared, off, th0, n = bench.build_problem("cfg2", "dense", 1, 0)
-    assert _plan_name(1000, 1, 2, 1e-5, PAIR)[1] == "em_pair_kernel<1, 2, 32, true>"
+    assert _plan_name(1000, 1, 2, 1e-5, PAIR)[1] == "em_pair_kernel<1, 2, 32, 32, true>"
     ref = _oracle(Y, U, V, np.zeros(n), th0, 1000, 1e-5)
     r = eng.em_batch(Y[0], U[0].T.copy(), V[0].T.copy(), th0, niter=1000, tol=1e-5)
     _check(r, ref, "cfg2")
@@ -195,6 +211,14 @@ def test_auto_choice(eng):
         a = eng.em_batch(y, u, v, small, niter=12, tol=0.0)
         b = eng.em_batch(y, u, v, small, niter=12, tol=0.0, algo=SCAN)
         assert np.array_equal(a["theta"], b["theta"]), mask
+    # T <= 512: four cells per wave once 32-cell workgroups fill the device (8192 cells), two cells
+    # per wave for 4096, the scan kernel for a few
+    y, u, v = _series(400, p, q, 4, "dense")
+    big8 = synth.make_init_packed(p, q, 8192, seed=3)
+    for n, same_as in ((8192, QUAD), (4096, PAIR), (24, SCAN)):
+        a = eng.em_batch(y, u, v, big8[:n], niter=8, tol=0.0)
+        b = eng.em_batch(y, u, v, big8[:n], niter=8, tol=0.0, algo=same_as)
+        assert np.array_equal(a["theta"], b["theta"]), n
 
 
 def test_large_scale_values(eng):
@@ -221,6 +245,7 @@ def test_singular_series_and_bad_shapes(eng):
         assert np.all(r["status"] == 2) and np.all(np.isnan(r["theta"])) and np.all(r["n_iter"] == 0)
         assert np.all(np.isnan(r["liks"]))
     # shapes outside the kernel: explicit PAIR is an error, AUTO goes elsewhere
+    assert _plan_name(600, 1, 2, 0.0, QUAD)[0] == -1 and _plan_name(512, 3, 3, 0.0, QUAD)[0] == -1
     for (T2, p2, q2) in ((64, 1, 2), (1025, 1, 2), (1000, 5, 2), (1000, 1, 5), (1000, 1, 4), (900, 4, 4)):
         assert _plan_name(T2, p2, q2, 0.0, PAIR)[0] == -1
         a, name = _plan_name(T2, p2, q2, 0.0, 0)

@@ -23,10 +23,10 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
     for case in range(n):
-        T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(513, 1025),
+        T = int(rng.choice([rng.integers(2, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(65, 513),
                             rng.integers(513, 1025), rng.integers(1100, 2049), rng.integers(2049, 4097), rng.integers(4097, 8193)]))
         p, q = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-        if 513 <= T <= 1024 and rng.random() < 0.7:      # the pair kernel's shapes
+        if 65 <= T <= 1024 and rng.random() < 0.7:       # the pair / quad kernels' shapes
             p, q = int(rng.integers(1, 5)), int(rng.integers(1, 5))
         S = int(rng.integers(1, 6))
         shared = bool(rng.integers(0, 2)) and S > 1
@@ -73,8 +73,9 @@ def main():
         ok = np.isfinite(ref[1])
         import ctypes
         algos = [1, 0, 2] if T <= 8192 and max(pe, qe) <= 8 else [1, 0]
-        if ldsr_amd._lib.lib().ldsr_em_plan(T, pe, qe, max(niter, 2), tol, 3, ctypes.create_string_buffer(8), 8) == 3:
-            algos.append(3)      # two cells per wave
+        for a in (3, 4):         # two / four cells per wave where they apply
+            if ldsr_amd._lib.lib().ldsr_em_plan(T, pe, qe, max(niter, 2), tol, a, ctypes.create_string_buffer(8), 8) == a:
+                algos.append(a)
         for algo in algos:     # serial, AUTO, scan kernel, pair kernel where it applies
             try:
                 r = ldsr_amd.em_batch(Y, U, V, th0, cell_offsets=off, niter=niter, tol=tol, algo=algo)

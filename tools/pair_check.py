@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU: the two-cells-per-wave kernel (algo 3) against the CPU oracle and the scan kernel (algo 2)
+"""GPU: the two- and four-cells-per-wave kernels (algo 3, 4) against the CPU oracle and the scan kernel (algo 2)
 on config-2 / config-5 shaped problems: python tools/pair_check.py"""
 import os
 import sys
@@ -24,7 +24,12 @@ def run(T, p, q, n, niter, tol, mask, seed=5):
     ref_th, ref_lik, ref_it, _ = O.em_batch(y[None], u.T[None].copy(), v.T[None].copy(),
                                             np.zeros(n, np.int32), th0, niter, tol, n_threads=8)
     ok = True
-    for algo in (2, 3):
+    import ctypes
+    algos = [2]
+    for a in (3, 4):
+        if ldsr_amd._lib.lib().ldsr_em_plan(T, p, q, max(niter, 2), tol, a, ctypes.create_string_buffer(8), 8) == a:
+            algos.append(a)
+    for algo in algos:
         t0 = time.time()
         r = ldsr_amd.em_batch(y, u, v, th0, niter=niter, tol=tol, algo=algo)
         dt = time.time() - t0
