@@ -32,3 +32,16 @@ def test_scan_kernel_register_budget():
     for tmpl in ("<1, 2, 16, 1, false, false, true>", "<4, 8, 16, 1, false, false, true>"):   # FIT forms
         vgpr, vspill, scratch, occ = get(tmpl)
         assert (vspill, scratch, occ) == (0, 0, 2), (tmpl, vgpr, vspill, scratch, occ)
+
+
+def test_pair_kernel_register_budget():
+    """The two-cells-per-wave kernels of BASELINE configs 2 (T=1000: L=32) and 5 (T=813: L=26) and
+    the four-cells-per-wave kernel of a short series: two waves per SIMD and no scratch (the first
+    cut of the pair kernel spilled 73 VGPRs until the reverse composite moved into F2)."""
+    import resource_usage
+    for tu, tmpl in (("em_pair_L32.hip", "<1, 2, 32, 32, false>"), ("em_pair_L32.hip", "<1, 2, 32, 32, true>"),
+                     ("em_pair_L26.hip", "<1, 4, 26, 32, false>"), ("em_quad_L13.hip", "<1, 2, 13, 16, false>")):
+        rows = resource_usage.table(os.path.join(ROOT, "ldsr_amd", "csrc", tu), tmpl)
+        assert len(rows) == 1, (tu, tmpl, [r[0] for r in rows])
+        _, vgpr, agpr, vspill, scratch, occ, sgpr, sspill = rows[0]
+        assert (vspill, scratch) == (0, 0) and occ >= 2 and vgpr <= 256, (tu, tmpl, vgpr, vspill, scratch, occ)
