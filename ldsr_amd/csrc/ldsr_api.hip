@@ -532,7 +532,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 int niter, double tol, int algo, double *d_theta, double *d_lik,
                                 int *d_n_iter, int *d_status, double *d_liks, int liks_nanfill,
                                 void *d_workspace, size_t workspace_bytes,
-                                const int *abort_flag = nullptr, int dense_hint = -1) {
+                                const int *abort_flag = nullptr, int dense_hint = -1,
+                                int *algo_used = nullptr) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -577,6 +578,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (algo == LDSR_ALGO_QUAD && !em_pair_supported(T, PP, QQ, 16))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
     const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;      // several cells per wave
+    if (algo_used) *algo_used = algo;
     const int cpb = cells_per_block(algo, T, PP, QQ, lpc);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
@@ -774,6 +776,7 @@ struct Slice {
     // inputs (host pointers already offset to the slice; `off` are local cell offsets)
     int device = 0, n_series = 0, T = 0, p = 0, q = 0, shared_uv = 0, niter = 0, algo = 0;
     int dense_hint = -1;     // 1: every y_t of every series is finite (AUTO's kernel choice with tol > 0)
+    int algo_used = 0;       // the algorithm the batch launch resolved to
     double tol = 0.0;
     const double *y = nullptr, *u = nullptr, *v = nullptr, *theta0 = nullptr;
     std::vector<int> off;
@@ -905,7 +908,7 @@ static int slice_run(Slice &S) {
         S.shared_uv, S.off.data(), (const double *)(A->dev + S.d_th0), S.niter, S.tol, S.algo,
         (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
         (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
-        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint);
+        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint, &S.algo_used);
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
     if (S.fuse && S.trace_on_device) {
@@ -1028,7 +1031,8 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
         int rc = em_batch_device_impl(
             S.device, A->stream, S.n_series, T, S.p, S.q, (const double *)(A->dev + S.d_y),
             S.u ? (const double *)(A->dev + S.d_u) : nullptr, S.v ? (const double *)(A->dev + S.d_v) : nullptr,
-            S.shared_uv, sel_off.data(), (const double *)(dw + W.theta0), niter, S.tol, S.algo,
+            S.shared_uv, sel_off.data(), (const double *)(dw + W.theta0), niter, S.tol,
+            S.algo_used ? S.algo_used : S.algo,       // the kernel of the batch run, whatever AUTO would pick for a few cells
             (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
             (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb, nullptr, S.dense_hint);
         if (rc) return rc;

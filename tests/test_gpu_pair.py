@@ -221,6 +221,32 @@ def test_auto_choice(eng):
         assert np.array_equal(a["theta"], b["theta"]), n
 
 
+def test_restart_grid_on_the_pair_kernel(eng, monkeypatch):
+    """ldsr_em_restart_grid with a launch large enough for AUTO to take the pair kernel: the
+    winner's trace and fit are those of the batch run's kernel, also when the traces do not fit
+    the device (cap forced to 0) and the winner is re-run alone -- a single cell, which AUTO by
+    itself would hand to the scan kernel."""
+    from ldsr_amd import synth
+    from oracle import oracle as O
+    T, p, q = 1000, 1, 2
+    y, u, v = _series(T, p, q, 6, "dense")
+    th0 = synth.make_init_packed(p, q, 4096, seed=9)
+    a = eng.em_restart_grid(y, u, v, th0, niter=40, tol=0.0)
+    ref = eng.em_batch(y, u, v, th0, niter=40, tol=0.0, algo=PAIR, return_liks=True)
+    w = int(a["winner"][0])
+    assert w == eng.select_restart(ref["lik"], ref["theta"], p, q)
+    assert np.array_equal(a["theta"][0], ref["theta"][w]) and a["lik"][0] == ref["lik"][w]
+    assert np.array_equal(a["liks"][0][:40], ref["liks"][w][:40])
+    monkeypatch.setenv("LDSR_LIKS_TRACE_MAX_BYTES", "0")
+    b = eng.em_restart_grid(y, u, v, th0, niter=40, tol=0.0)
+    for k in ("winner", "theta", "lik", "n_iter", "X", "Y", "V", "J"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["liks"], b["liks"], equal_nan=True)
+    fit = O.kalman_smoother(y, u, v, ref["theta"][w])     # the winner's fit (packed theta)
+    assert parity_close(np.ravel(a["X"][0]), np.ravel(fit["X"]), RTOL, ATOL)
+    assert parity_close(np.ravel(a["V"][0]), np.ravel(fit["V"]), RTOL, ATOL)
+
+
 def test_large_scale_values(eng):
     """y scaled by 1e+-8 (R and Q collapse / explode): the scaled step matrix of the dense F1 and
     the folded log-determinant keep every product in range."""
