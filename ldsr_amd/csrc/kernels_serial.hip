@@ -93,13 +93,14 @@ __device__ __forceinline__ double prep_wave_sum(double x) {
     return x;
 }
 
-// One workgroup (4 waves) per series.  Every theta-independent statistic is a wave-parallel
+// One workgroup (16 waves) per series.  Every theta-independent statistic is a wave-parallel
 // strided sum over t followed by a shuffle reduction (fixed summation tree: deterministic);
-// statistics are dealt round-robin to the 4 waves.
-__global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
+// statistics are dealt round-robin to the waves.
+__global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
     const int s = blockIdx.x;
     const int T = prm.T, p = prm.p, q = prm.q, PP = prm.PP, QQ = prm.QQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, n_waves = NT >> 6;        // 1024 threads: the loops below are latency bound
     const double *y = prm.y + (long)s * T;
     const bool own_uv = (!prm.shared_uv) || s == 0;
     const double *u = prm.u ? prm.u + (prm.shared_uv ? 0 : (long)s * T * p) : nullptr;
@@ -113,24 +114,24 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
 
     if (tid == 0 && prm.queue) prm.queue[s] = 0;
     // prepared copies
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NT) {
         const double yv = y[t];
         yp[t] = yv;
         prm.yz[(long)s * T + t] = isfinite(yv) ? yv : 0.0;
     }
     if (own_uv) {
-        for (int i = tid; i < T * PP; i += 256) {
+        for (int i = tid; i < T * PP; i += NT) {
             const int t = i / PP, k = i - t * PP;
             // u[:,T-1] is never read by the reference (src/EM.cpp:74,190-193): zero it
             up[i] = (u && k < p && t < T - 1) ? u[(long)t * p + k] : 0.0;
         }
-        for (int i = tid; i < T * QQ; i += 256) {
+        for (int i = tid; i < T * QQ; i += NT) {
             const int t = i / QQ, k = i - t * QQ;
             vp[i] = (v && k < q) ? v[(long)t * q + k] : 0.0;
         }
     }
     // identity / zero padding of the statistics
-    for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += 256) {
+    for (int i = tid; i < LDSR_MAXPQ * LDSR_MAXPQ; i += NT) {
         const double id = ((i / LDSR_MAXPQ) == (i % LDSR_MAXPQ)) ? 1.0 : 0.0;
         sc.Svv_inv[i] = id;
         sc.Tuu_inv[i] = id;
@@ -142,19 +143,21 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     // statistic ids: [0, q*q) Svv(k,l); [.., +p*p) Tuu(k,l); [.., +q) Syv(k); last: Syy + counts
     const int nqq = v ? q * q : 0, npp = u ? p * p : 0, nq = v ? q : 0;
     const int n_stat = nqq + npp + nq + 1;
-    for (int id = wave; id < n_stat; id += 4) {
+    for (int id = wave; id < n_stat; id += n_waves) {
         double acc = 0.0;
         if (id < nqq) {
             const int k = id / q, l = id - k * q;
+            if (l < k) continue;                     // symmetric: (l, k) is written by (k, l)
             for (int t = lane; t < T; t += 64)
                 acc += isfinite(y[t]) ? v[(long)t * q + k] * v[(long)t * q + l] : 0.0;   // :161
             acc = prep_wave_sum(acc);
-            if (lane == 0) sc.Svv_inv[k * LDSR_MAXPQ + l] = acc;
+            if (lane == 0) { sc.Svv_inv[k * LDSR_MAXPQ + l] = acc; sc.Svv_inv[l * LDSR_MAXPQ + k] = acc; }
         } else if (id < nqq + npp) {
             const int j = id - nqq, k = j / p, l = j - k * p;
+            if (l < k) continue;
             for (int t = lane; t < T - 1; t += 64) acc += u[(long)t * p + k] * u[(long)t * p + l];   // :193
             acc = prep_wave_sum(acc);
-            if (lane == 0) sc.Tuu_inv[k * LDSR_MAXPQ + l] = acc;
+            if (lane == 0) { sc.Tuu_inv[k * LDSR_MAXPQ + l] = acc; sc.Tuu_inv[l * LDSR_MAXPQ + k] = acc; }
         } else if (id < nqq + npp + nq) {
             const int k = id - nqq - npp;
             for (int t = lane; t < T; t += 64) {
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
         auto build_image = [&](double *im, int L, int NL) {
             const int K = 1 + PP + QQ, KP = (K + 1) / 2;
             const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
-            for (int e = tid; e < NL * L * KP * 2; e += 256) {
+            for (int e = tid; e < NL * L * KP * 2; e += NT) {
                 const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
                 const int i = 2 * m + h;
                 const int t = l * (L - 1) + min(l, rp) + j;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void series_prep_kernel(PrepParams prm) {
     {   // cooperative copy of the result to global memory
         const int *src = reinterpret_cast<const int *>(&sc);
         int *dst = reinterpret_cast<int *>(prm.sc + s);
-        for (int i = tid; i < (int)(sizeof(SeriesConst) / sizeof(int)); i += 256) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(SeriesConst) / sizeof(int)); i += NT) dst[i] = src[i];
     }
 }
 
@@ -677,7 +680,7 @@ void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len) {
 }
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream) {
-    hipLaunchKernelGGL(series_prep_kernel, dim3(n_series), dim3(256), 0, stream, prm);
+    hipLaunchKernelGGL(series_prep_kernel, dim3(n_series), dim3(1024), 0, stream, prm);
     return hipGetLastError();
 }
 
