@@ -1,6 +1,8 @@
-// em_pair_impl.h -- two cells per wavefront: the parallel-in-time EM kernel for series of 65 to
-// 1024 steps with narrow inputs (T <= 32 L, 3 <= L <= 32, padded p, q <= 4; kernels_scan.hip
-// pair_plan() has the exact ranges).
+// em_pair_impl.h -- two or four cells per wavefront: the parallel-in-time EM kernel for series of
+// 65 to 1024 steps with narrow inputs (LPC = 32 or 16 lanes per cell, T <= LPC L, L <= 32, padded
+// p, q <= 4; kernels_scan.hip pair_plan() has the exact ranges).  The text below describes two
+// cells per wave (LPC = 32); with LPC = 16 a cell is one 16-lane DPP row, both scans are the four
+// row-shift rounds and every per-wave item is shared by four cells.
 //
 // Why.  In em_scan_kernel (one cell per 64-lane wave, em_scan_impl.h) half of the ~1500 VALU
 // instructions of an EM iteration at T = 1000 do not depend on the chunk length: the two
@@ -14,7 +16,7 @@
 // What makes it fit.  Three per-step values (J_t, g_t, h_t: em_scan_impl.h) must survive from
 // the forward to the backward sweep; at L = 32 that is 96 doubles per lane -- 192 VGPRs, too
 // many for two waves per SIMD.  J_t and g_t stay in registers; h_t (needed only by the variance
-// recursion) goes through a per-wave LDS strip [step][lane] (one ds_write_b64 and two
+// recursion) goes through a per-wave LDS strip [step][lane] (one ds_write_b64 and one
 // ds_read_b64 per step, conflict-free), which with the 32-lane series image fills the CU's 160 KiB
 // exactly at eight waves.  Nothing but theta / lik / n_iter / status ever goes to HBM.
 //
