@@ -71,6 +71,49 @@ def test_argument_validation_without_gpu():
     assert L.ldsr_em_workspace_bytes(1, 9000, 1, 2, 64, 0) > 0      # AUTO: serial kernel
 
 
+def test_launch_plan_of_every_shape():
+    """ldsr_em_plan is host logic (no GPU): which kernel a device-filling launch of a shape gets.
+    Four cells per wave up to T = 512, two up to 1024 (narrow inputs, where eight waves per CU fit),
+    one to four waves per cell up to T = 8192 and p, q <= 8, one thread per cell beyond; with
+    tol > 0 AUTO reports what the device entry runs (scan kernel + work queue)."""
+    import ctypes as C
+    from ldsr_amd import _lib
+    L = _lib.lib()
+
+    def plan(T, p, q, tol=0.0, algo=0):
+        buf = C.create_string_buffer(160)
+        a = L.ldsr_em_plan(T, p, q, 100, float(tol), algo, buf, 160)
+        return a, buf.value.decode()
+
+    assert plan(1000, 1, 2) == (3, "em_pair_kernel<1, 2, 32, 32, false>")          # BASELINE config 2
+    assert plan(813, 1, 3) == (3, "em_pair_kernel<1, 4, 26, 32, false>")           # config 5
+    assert plan(1000, 4, 8) == (2, "em_scan_kernel<4, 8, 16, 1, false, false, false>")   # config 3
+    assert plan(2000, 1, 4) == (2, "em_scan_kernel<1, 4, 32, 1, false, false, false>")   # config 4
+    assert plan(1000, 1, 2, 1e-5) == (2, "em_scan_kernel<1, 2, 16, 1, true, false, false>")
+    assert plan(1000, 1, 2, 1e-5, 3) == (3, "em_pair_kernel<1, 2, 32, 32, true>")
+    assert plan(85, 1, 2) == (4, "em_pair_kernel<1, 2, 6, 16, false>")
+    assert plan(213, 3, 3) == (4, "em_pair_kernel<4, 4, 14, 16, false>")           # the NP test slice
+    assert plan(85, 7, 7)[1].startswith("em_scan_kernel<8, 8,")                     # the P1 known-answer case
+    assert plan(4000, 2, 2)[1].startswith("em_scan_kernel<2, 2, 32, 2, true, true, false>")
+    assert plan(9000, 1, 1)[0] == 1 and plan(500, 9, 1)[0] == 1                      # serial kernel
+    # the pair family's limits: T, widths, and the eight-waves-per-CU rule for wide inputs
+    for T, p, q, a3, a4 in ((64, 1, 2, -1, -1), (65, 1, 2, 3, 4), (512, 1, 2, 3, 4), (513, 1, 2, 3, -1),
+                            (1024, 1, 2, 3, -1), (1025, 1, 2, -1, -1), (1000, 1, 4, -1, -1), (928, 1, 4, 3, -1),
+                            (800, 4, 4, 3, -1), (900, 4, 4, -1, -1), (512, 3, 3, 3, -1), (400, 3, 3, 3, 4),
+                            (1000, 5, 1, -1, -1), (300, 1, 5, -1, -1)):
+        assert plan(T, p, q, 0.0, 3)[0] == a3, (T, p, q)
+        assert plan(T, p, q, 0.0, 4)[0] == a4, (T, p, q)
+    # every T of the family maps its steps onto the lanes exactly (1 <= rp <= nl <= lanes per cell)
+    for lpc, algo, Tmax in ((32, 3, 1024), (16, 4, 512)):
+        for T in range(65, Tmax + 1):
+            a, name = plan(T, 1, 2, 0.0, algo)
+            assert a == algo, (T, algo)
+            Lc = int(name.split(",")[2])
+            nl = -(-T // Lc)
+            rp = T - nl * (Lc - 1)
+            assert nl <= lpc and 1 <= rp <= nl and Lc <= 32, (T, Lc, nl, rp)
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product path must fail loudly, never compute on the host."""
     import ldsr_amd
