@@ -286,6 +286,12 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_DENSE_F1_POW    // dense series: chunk composite = power of the 2x2 block + row recursion
 #define LDSR_DENSE_F1_POW 1
 #endif
+#ifndef LDSR_DENSE_F1_POW_MAXP   // widest padded inputs that take that form
+#define LDSR_DENSE_F1_POW_MAXP 4
+#endif
+#ifndef LDSR_DENSE_F1_POW_MAXQ
+#define LDSR_DENSE_F1_POW_MAXQ 4
+#endif
 #ifndef LDSR_GIMG_PREFETCH   // the same pipeline for the global image (same-box A/B: 2-5 % slower -- off)
 #define LDSR_GIMG_PREFETCH 0
 #endif
@@ -513,7 +519,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
             if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (DENSE && L <= 16 && PP <= 4 && QQ <= 4 && LDSR_DENSE_F1_POW) {
+        if constexpr (DENSE && L <= 16 && PP <= LDSR_DENSE_F1_POW_MAXP && QQ <= LDSR_DENSE_F1_POW_MAXQ && LDSR_DENSE_F1_POW) {
             // Fully observed series: every step has the SAME 2x2 block Bm = [[alpha, Q],[C2R, 1]],
             // so the chunk's 2x2 block is a power of it -- lane independent, by binary
             // exponentiation -- and only the third row (a, b, c) of the composite needs the
