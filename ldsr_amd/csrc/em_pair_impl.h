@@ -191,7 +191,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             prenorm(M);
         }
 
-        // ------------------------------------------------ forward scan over the half's 32 lanes
+        // ------------------------------------------------ forward scan over the cell's LPC lanes
         M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
         M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
         M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
@@ -439,8 +439,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     }
 }
 
-// One workgroup = up to 8 waves = up to 16 cells of ONE series.  Static: wave w owns cells
-// c0 + 2w, c0 + 2w + 1 of the block (nc of them).  QUEUE: (c0, nc) is the series' whole range and
+// One workgroup = up to 8 waves = up to 16 (LPC = 32) or 32 (LPC = 16) cells of ONE series.
+// Static: wave w owns cells c0 + CPW w .. c0 + CPW w + CPW - 1 of the block (nc of them), CPW = 64 / LPC.  QUEUE: (c0, nc) is the series' whole range and
 // every half pulls cells from the per-series counter.
 template <int PP, int QQ, int L, int LPC, bool QUEUE>
 __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
