@@ -242,14 +242,19 @@ class Job:
         ws_ptr = (self.d_ws.data_ptr() + 255) & ~255
         off = (C.c_int * (self.S + 1))(*[int(x) for x in loc_off])
         stream = torch.cuda.current_stream(dev)
+        # what the generator knows about its own mask and hands over like the host-pointer entries
+        # find it from y: the number of leading steps that are missing in EVERY series
+        fin = np.isfinite(Y)
+        self.lead = int(min((np.argmax(r) if r.any() else Y.shape[1]) for r in fin)) if os.environ.get(
+            "LDSR_BENCH_NO_LEAD") is None else 0
 
         def step():
-            _lib.check(L.ldsr_em_batch_device(
+            _lib.check(L.ldsr_em_batch_device_lead(
                 local_rank, C.c_void_p(stream.cuda_stream), self.S, T, p, q, self.d_y.data_ptr(),
                 self.d_u.data_ptr(), self.d_v.data_ptr(), self.shared_uv, off,
                 self.d_th0.data_ptr(), niter, tol, algo, self.d_th.data_ptr(),
                 self.d_lik.data_ptr(), self.d_nit.data_ptr(), self.d_st.data_ptr(), None,
-                C.c_void_p(ws_ptr), self.wsb))
+                C.c_void_p(ws_ptr), self.wsb, self.lead))
         self.step = step
 
     def units(self, niter, tol):
@@ -320,8 +325,8 @@ def main():
               build_problem(args.workload, args.mask, world, rank, scaling), T, p, q, niter,
               args.tol, args.algo)
     name_buf = C.create_string_buffer(160)
-    algo_resolved = L.ldsr_em_plan(T, p, q, niter, args.tol, args.algo, name_buf, 160)
-    kernel_name = name_buf.value.decode()
+    algo_resolved = L.ldsr_em_plan_lead(T, p, q, niter, args.tol, args.algo, job.lead, name_buf, 160)
+    kernel_name = name_buf.value.decode()      # (replaced below by what the first launch really ran)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -362,6 +367,8 @@ def main():
         return dt, units_rank, units_all, kern_ms
 
     dt, units_rank, units_all, kern_ms = timed(job, True)
+    if L.ldsr_last_em_kernel(local_rank, name_buf, 160) == 0:      # the kernel the timed launches ran
+        kernel_name = name_buf.value.decode()
 
     strong = None
     if world > 1 and single and scaling == "weak":

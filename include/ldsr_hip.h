@@ -174,6 +174,22 @@ int ldsr_em_batch_device(int device, void *stream, int n_series, int T, int p, i
  * take the pair kernel when every series is fully observed. */
 int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len);
 
+/* The same two with one more piece of knowledge about the data: the first lead_steps time steps of
+ * EVERY series are missing (paleo-type series: centuries before the instrumental period; 0 = none
+ * or unknown).  LDSR_ALGO_AUTO then handles that lead in closed form and sweeps only the tail
+ * (em_pair_impl.h, LEAD).  The host-pointer entries find the lead themselves. */
+int ldsr_em_batch_device_lead(int device, void *stream, int n_series, int T, int p, int q,
+                              const double *d_y, const double *d_u, const double *d_v,
+                              int shared_uv, const int *cell_offsets, const double *d_theta0,
+                              int niter, double tol, int algo, double *d_theta, double *d_lik,
+                              int *d_n_iter, int *d_status, double *d_liks, void *d_workspace,
+                              size_t workspace_bytes, int lead_steps);
+int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
+                      char *buf, size_t len);
+/* Name of the EM kernel of the most recent EM launch on `device` (what AUTO actually chose for that
+ * launch's size and data); -1 if there was none. */
+int ldsr_last_em_kernel(int device, char *buf, size_t len);
+
 /* Batched Kalman_smoother: one E-step for each cell's theta.  Host pointers.
  * X, Y, V, J: [n_cells][T] (any may be NULL); lik: [n_cells].  stdlik as src/EM.cpp:124. */
 int ldsr_smooth_batch(int device, int n_series, int T, int p, int q, const double *y,

@@ -30,6 +30,12 @@ SIGNATURES = {
     "ldsr_em_restart_groups": (C.c_int, [C.c_int, _ip, C.c_int, _vp, C.c_int, C.c_double, C.c_int]),
     "ldsr_em_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
                                C.c_size_t]),
+    "ldsr_em_plan_lead": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                    C.c_char_p, C.c_size_t]),
+    "ldsr_em_batch_device_lead": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                            _vp, C.c_int, _ip, _vp, C.c_int, C.c_double, C.c_int, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
+    "ldsr_last_em_kernel": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "ldsr_set_interrupt_callback": (C.c_int, [_vp, _vp]),
     "ldsr_em_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldsr_em_batch_device": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,

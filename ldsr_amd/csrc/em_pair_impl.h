@@ -40,9 +40,10 @@ __host__ __device__ constexpr long pair_strip_doubles(int L) { return (long)64 *
 
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
-template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE>
+template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
-                                             int s, int c0, int nc, int lane, int wave) {
+                                             const double *lu, int s, int c0, int nc, int lane, int wave) {
+    static_assert(!(LEAD && DENSE), "a lead of missing steps and a fully observed series exclude each other");
     constexpr int KP = scan_pairs(PP, QQ);
     static_assert(LPC == 32 || LPC == 16, "two or four cells per wave");
     constexpr int CPW = 64 / LPC;                         // cells per wave
@@ -52,7 +53,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     auto Yat = [&](int j) { return val(j, 0); };
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
-    const int T = prm.T;
+    // LEAD: the first `lead` steps of every series of the launch are unobserved and are handled in
+    // closed form (below); the sweeps work on the tail [lead, T) only, all indices tail relative
+    const int lead = LEAD ? prm.lead : 0;
+    const int T = prm.T - lead;              // steps of the sweeps
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
     const int n_obs = sc->n_obs;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 
     unsigned obsmask = 0;
     if (!DENSE && act) {
-        const double *gy = prm.yp + (long)s * T;
+        const double *gy = prm.yp + (long)s * prm.T + lead;
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const double yv = (j < L - 1 || tail) ? gy[t0 + j] : NAN;
@@ -109,6 +113,107 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
             return bu;
         };
+
+        // ------------------------------------------------ LEAD: the all-missing first `lead` steps
+        // Over unobserved steps K_t = 0 (src/EM.cpp:82-84): Xp_{t+1} = A Xp_t + B u_t and
+        // Vp_{t+1} = A^2 Vp_t + Q are affine with constant multipliers, the smoother's corrections are
+        // pure products,  Xs_t - Xp_t = J_t (Xs_{t+1} - Xp_{t+1}),  Vs_t - Vp_t = J_t^2 (Vs_{t+1} - Vp_{t+1}),
+        // and  prod_{k=t}^{t1-1} J_k = A^(t1-t) Vp_t / Vp_t1 =: c_t  telescopes (J_k = A Vp_k / Vp_{k+1},
+        // :98-100).  So with (delta, eps) = (Xs - Xp, Vs - Vp) at the first step t1 of the tail,
+        //     Xs_t = Xp_t + c_t delta,   Vs_t = Vp_t + c_t^2 eps          for every t < t1,
+        // and the lead's share of every M-step sum (:180-193) is a polynomial in (delta, eps) whose
+        // coefficients are data sums of ONE forward pass -- no per-step storage, no backward pass,
+        // no 3x3 scan, ~20 fp64 operations per step against ~85 in the masked sweeps.  The sweeps
+        // below run on the tail [t1, T) from (Xp_t1, Vp_t1).  (tools/lead_closed_form_probe.py
+        // checks the formulas against the CPU oracle's smoother: 6e-16.)
+        // Lane l of the cell owns lead steps [l nA, (l+1) nA); A^(t1-t) is carried as mantissa x
+        // 2^exponent (it starts at 2^-thousands for the early lanes and must neither underflow for
+        // good nor lose its mantissa on the way up to 1).
+        double x_t1 = th.mu1, v_t1 = th.V1, c_first = 1.0;
+        double lS[LEAD ? 7 + 4 * PP : 1];
+        if constexpr (LEAD) {
+            const int nA = (lead + LPC - 1) / LPC;
+            const int tA = vl * nA;                                  // first lead step of this lane
+            const int nj = min(max(lead - tA, 0), nA);               // ... and how many it has
+            const double *lup = lu + (long)vl * PP;                  // [step j][lane][PP]
+            auto bu_lead = [&](int j) {
+                double bu = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], lup[(long)j * LPC * PP + p_], bu);
+                return bu;
+            };
+            // pass 1: this lane's composites of x -> A x + B u_t and V -> A^2 V + Q
+            double al = 1.0, bl = 0.0, a2l = 1.0, ql = 0.0;
+            for (int j = 0; j < nj; j++) {
+                bl = fma(A, bl, bu_lead(j));
+                ql = fma(A2, ql, Q);
+                al *= A;
+                a2l *= A2;
+            }
+            // inclusive scan of both affine maps over the cell's lanes
+#define LSCAN_ROUND(AB, BB, A2B, QB)                                       \
+            {                                                              \
+                const double ab = AB, bb = BB, a2b = A2B, qb = QB;         \
+                bl = fma(al, bb, bl);  al *= ab;                           \
+                ql = fma(a2l, qb, ql); a2l *= a2b;                         \
+            }
+            LSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl), dpp1<DPP_ROW_SHR(1)>(a2l), dppz<DPP_ROW_SHR(1)>(ql))
+            LSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl), dpp1<DPP_ROW_SHR(2)>(a2l), dppz<DPP_ROW_SHR(2)>(ql))
+            LSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl), dpp1<DPP_ROW_SHR(4)>(a2l), dppz<DPP_ROW_SHR(4)>(ql))
+            LSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl), dpp1<DPP_ROW_SHR(8)>(a2l), dppz<DPP_ROW_SHR(8)>(ql))
+            if constexpr (LPC == 32)
+                LSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)),
+                            (dppd<DPP_ROW_BCAST15, 0xA>(1.0, a2l)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, ql)))
+#undef LSCAN_ROUND
+            double Xl = fma(al, th.mu1, bl), Vl = fma(a2l, th.V1, ql);      // after this lane's steps
+            x_t1 = shfl_d(Xl, hbase | (LPC - 1));                          // = at t1 (idle lanes pass through)
+            v_t1 = shfl_d(Vl, hbase | (LPC - 1));
+            Xl = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xl);                       // entry of this lane
+            Vl = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, Vl);
+            if (vl == 0) { Xl = th.mu1; Vl = th.V1; }
+            const double rV1 = fast_rcp(v_t1);
+            // d = A^(t1 - t) at this lane's first step, as m 2^e (|A| clamped away from 0: beyond
+            // a few steps the true value is below 1e-300 anyway)
+            const double As = fabs(A) < 1e-150 ? copysign(1e-150, A) : A;
+            const double rA = fast_rcp(As);
+            const int k0 = lead - tA;
+            const double xl2 = (double)k0 * (log_pos(fabs(As)) * 1.4426950408889634074);
+            const double ef = fmin(fmax(floor(xl2), -1.0e6), 1.0e6);
+            double dm = exp2(xl2 - ef);
+            int de = (int)ef;
+            if (As < 0.0 && (k0 & 1)) dm = -dm;
+#pragma unroll
+            for (int i = 0; i < 7 + 4 * PP; i++) lS[i] = 0.0;
+            // pass 2: the data sums; c = c_t, c1 = c_{t+1}
+            double c = __builtin_amdgcn_ldexp(dm, de) * (Vl * rV1);
+            c_first = c;
+            for (int j = 0; j < nj; j++) {
+                double ul[PP];
+                double bu = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) { ul[p_] = lup[(long)j * LPC * PP + p_]; bu = fma(th.B[p_], ul[p_], bu); }
+                const double Xl1 = fma(A, Xl, bu), Vl1 = fma(A2, Vl, Q);
+                dm *= rA;
+                if ((j & 7) == 7) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
+                const double c1 = __builtin_amdgcn_ldexp(dm, de) * (Vl1 * rV1);
+                lS[0] = fma(Xl, Xl, lS[0]);                   // sum Xp^2
+                lS[1] += Vl;                                  // sum Vp
+                lS[2] = fma(c, Xl, lS[2]);                    // sum c Xp
+                lS[3] = fma(c, c, lS[3]);                     // sum c^2
+                lS[4] = fma(Xl1, Xl, lS[4]);                  // sum Xp_{t+1} Xp_t
+                lS[5] = fma(c1, Xl, fma(c, Xl1, lS[5]));      // sum c_{t+1} Xp_t + c_t Xp_{t+1}
+                lS[6] = fma(c, c1, lS[6]);                    // sum c_t c_{t+1}
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    lS[7 + p_] = fma(Xl1, ul[p_], lS[7 + p_]);                    // sum Xp_{t+1} u_t
+                    lS[7 + PP + p_] = fma(c1, ul[p_], lS[7 + PP + p_]);           // sum c_{t+1} u_t
+                    lS[7 + 2 * PP + p_] = fma(ul[p_], Xl, lS[7 + 2 * PP + p_]);   // sum u_t Xp_t
+                    lS[7 + 3 * PP + p_] = fma(c, ul[p_], lS[7 + 3 * PP + p_]);    // sum c_t u_t
+                }
+                Xl = Xl1; Vl = Vl1; c = c1;
+            }
+            c_first = shfl_d(c_first, hbase);       // c_0 (lane 0 of the cell)
+        }
 
         // ------------------------------------------------ F1: compose this lane's step matrices;
         // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
@@ -200,7 +305,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
         // exit state of this lane's chunk, then the entry state = exit state of the lane before
         // (lane 0 of each half: the cell's initial state)
-        const double n_in = th.V1, d_in = 1.0, x_in = th.mu1;
+        const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
         double n_e = fma(M.m00, n_in, M.m01 * d_in);
         double d_e = fma(M.m10, n_in, M.m11 * d_in);
         double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
@@ -361,9 +466,14 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         Sums<PP, QQ> S;
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);
-            constexpr int NR = NB + QQ + 2 * PP;
+            constexpr int NT = NB + QQ + 2 * PP;                     // the sweeps' sums
+            constexpr int NR = NT + (LEAD ? 7 + 4 * PP : 0);         // + the lead's
             static_assert(NR <= 2 * LPC, "reduction gather handles two slots per lane");
             double red[NR];
+            if constexpr (LEAD) {
+#pragma unroll
+                for (int i = 0; i < 7 + 4 * PP; i++) red[NT + i] = lS[i];
+            }
             red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
             if (!DENSE) red[5] = aSxx;
 #pragma unroll
@@ -383,6 +493,21 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             }
             S.X0 = shfl_d(Xn, hbase);                // :218
             S.V0 = shfl_d(Vn, hbase);                // :219
+            if constexpr (LEAD) {
+                // (delta, eps) at the tail's first step close the lead's sums; mu1 / V1 come from t = 0
+                const double dlt = S.X0 - x_t1, eps = S.V0 - v_t1;
+                const double d2e = fma(dlt, dlt, eps);
+                const double *l = red + NT;
+                red[2] += (l[0] + l[1]) + fma(2.0 * dlt, l[2], d2e * l[3]);                 // sum Xs^2 + Vs
+                red[1] += l[4] + fma(dlt, l[5], fma(d2e, l[6], A * l[1]));                  // sum Xs' Xs + Vs' J
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    red[NB + QQ + p_] += fma(dlt, l[7 + PP + p_], l[7 + p_]);               // Tx1u
+                    red[NB + QQ + PP + p_] += fma(dlt, l[7 + 3 * PP + p_], l[7 + 2 * PP + p_]);   // Tux
+                }
+                S.X0 = fma(c_first, dlt, th.mu1);
+                S.V0 = fma(c_first * c_first, eps, th.V1);
+            }
             const double term0 = fma(S.X0, S.X0, S.V0);
             const unsigned long long negm = __ballot(sneg < 0);
             const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
@@ -442,7 +567,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 // One workgroup = up to 8 waves = up to 16 (LPC = 32) or 32 (LPC = 16) cells of ONE series.
 // Static: wave w owns cells c0 + CPW w .. c0 + CPW w + CPW - 1 of the block (nc of them), CPW = 64 / LPC.  QUEUE: (c0, nc) is the series' whole range and
 // every half pulls cells from the per-series counter.
-template <int PP, int QQ, int L, int LPC, bool QUEUE>
+template <int PP, int QQ, int L, int LPC, bool QUEUE, bool LEAD = false>
 __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr long IMG = pair_image_doubles(L, PP, QQ, LPC);
@@ -452,6 +577,14 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *gimg = prm.img2 + (long)s * prm.img2_stride;
     for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+    // LEAD: the (whitened) u_t of the all-missing first prm.lead steps, [step of the lane][lane][PP],
+    // behind the strips
+    double *lu = smem + IMG + (long)(blockDim.x >> 6) * pair_strip_doubles(L);
+    if constexpr (LEAD) {
+        const int n3 = ((prm.lead + LPC - 1) / LPC) * LPC * PP;
+        const double *g3 = prm.img3 + (long)s * prm.img3_stride;
+        for (int i = threadIdx.x; i < n3; i += blockDim.x) lu[i] = g3[i];
+    }
     __syncthreads();
     const SeriesConst *sc = prm.sc + s;
     if (sc->status != 0) {
@@ -472,8 +605,12 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     if (!QUEUE && (64 / LPC) * wave >= nc) return;    // whole wave leaves; no barrier follows
     double *hs = smem + IMG + (long)wave * pair_strip_doubles(L) + lane;
     const bool dense = sc->n_obs == prm.T;
-    if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
-    else em_pair_body<PP, QQ, L, LPC, false, QUEUE>(prm, smem, hs, s, c0, nc, lane, wave);
+    if constexpr (LEAD) {
+        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+    } else {
+        if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+        else em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+    }
 }
 
 struct PairPlan {
@@ -487,3 +624,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc);
 template <int L, int LPC>
 hipError_t launch_em_pair_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,
                             hipStream_t stream);
+// doubles of the lead image of one series (LEAD kernels)
+__host__ __device__ constexpr long pair_lead_doubles(int lead, int LPC, int PP) {
+    return (long)((lead + LPC - 1) / LPC) * LPC * PP;
+}

@@ -126,15 +126,15 @@ void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles) {
     *L = p.L;
     *img_doubles = p.ok ? pair_image_doubles(p.L, PP, QQ, lpc) : 0;
 }
-void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len) {
+void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead) {
     const PairPlan p = pair_plan(T, PP, QQ, lpc);
-    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s>", PP, QQ, p.L, lpc, queue ? "true" : "false");
+    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s%s>", PP, QQ, p.L, lpc, queue ? "true" : "false", lead ? ", true" : "");
 }
 
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,
                           hipStream_t stream) {
-    const PairPlan p = pair_plan(prm.T, PP, QQ, lpc);
-    if (!p.ok || !prm.img2) return hipErrorInvalidValue;
+    const PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc);     // (LEAD form: the tail's plan)
+    if (!p.ok || !prm.img2 || (prm.lead > 0 && !prm.img3)) return hipErrorInvalidValue;
 #define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \
                                              : launch_em_pair_L<Lv, 16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
     switch (p.L) {

@@ -220,13 +220,15 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
         // pairs, pair m of step j of virtual lane l at [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where
         // missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
         // kernel's (32 lanes, its own chunk length).
-        auto build_image = [&](double *im, int L, int NL) {
+        // toff: the image covers the steps [toff, T) (the pair kernel's LEAD form), else 0
+        auto build_image = [&](double *im, int L, int NL, int toff) {
             const int K = 1 + PP + QQ, KP = (K + 1) / 2;
-            const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+            const int Tt = T - toff;
+            const int nl = (Tt + L - 1) / L, rp = Tt - nl * (L - 1);
             for (int e = tid; e < NL * L * KP * 2; e += NT) {
                 const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
                 const int i = 2 * m + h;
-                const int t = l * (L - 1) + min(l, rp) + j;
+                const int t = toff + l * (L - 1) + min(l, rp) + j;
                 const bool ok = l < nl && (j < L - 1 || l < rp);
                 double val = 0.0;
                 if (ok) {
@@ -246,8 +248,21 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
                 im[e] = val;
             }
         };
-        if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL);
-        if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, prm.NL2);
+        if (prm.img) build_image(prm.img + (long)s * prm.img_stride, prm.L, prm.NL, 0);
+        if (prm.img2) build_image(prm.img2 + (long)s * prm.img2_stride, prm.L2, prm.NL2, prm.img3 ? prm.lead : 0);
+        if (prm.img3) {
+            // whitened u_t of the lead: lane l owns steps [l nA, (l+1) nA), element [(j NL2 + l) PP + k]
+            double *im3 = prm.img3 + (long)s * prm.img3_stride;
+            const int NL2 = prm.NL2, nA = (prm.lead + NL2 - 1) / NL2;
+            for (int e = tid; e < nA * NL2 * PP; e += NT) {
+                const int k = e % PP, l = (e / PP) % NL2, j = e / (PP * NL2);
+                const int t = l * nA + j;
+                double val = 0.0;
+                if (t < prm.lead && j < nA && u && k < p && t < T - 1)
+                    for (int jj = 0; jj <= k; jj++) val = fma(sc.Lu_inv[k * LDSR_MAXPQ + jj], u[(long)t * p + jj], val);
+                im3[e] = val;
+            }
+        }
     }
     {   // cooperative copy of the result to global memory
         const int *src = reinterpret_cast<const int *>(&sc);

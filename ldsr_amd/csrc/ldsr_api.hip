@@ -18,6 +18,7 @@
 
 #include "../../include/ldsr_hip.h"
 #include "ldsr_kernels.h"
+#include "em_pair_impl.h"      // (layout constants only)
 
 static thread_local std::string g_err;
 
@@ -361,6 +362,35 @@ static int device_cu_count(int device) {
 }
 
 // LDSR_PAIR=0 in the environment keeps AUTO off the two-cells-per-wave kernel (same-box A/B runs)
+// LDSR_FORCE_FILL=1: AUTO treats every launch as large enough for the pair family (tests and the
+// fuzzer exercise AUTO's choices with a handful of cells)
+static bool force_fill() {
+    static const bool on = [] { const char *e = getenv("LDSR_FORCE_FILL"); return e && e[0] == '1'; }();
+    return on;
+}
+
+// name of the EM kernel of the most recent launch per device (ldsr_last_em_kernel)
+static std::mutex g_last_mu;
+static std::vector<std::string> g_last_kernel;
+static void remember_kernel(int device, const char *name) {
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    if ((int)g_last_kernel.size() <= device) g_last_kernel.resize((size_t)device + 1);
+    g_last_kernel[(size_t)device] = name;
+}
+extern "C" int ldsr_last_em_kernel(int device, char *buf, size_t len) {
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    if (device < 0 || (int)g_last_kernel.size() <= device || g_last_kernel[(size_t)device].empty() || !buf || !len)
+        return -1;
+    snprintf(buf, len, "%s", g_last_kernel[(size_t)device].c_str());
+    return 0;
+}
+
+// LDSR_LEAD=0 keeps AUTO off the closed-form lead of the pair family (same-box A/B runs)
+static bool lead_enabled() {
+    static const bool on = [] { const char *e = getenv("LDSR_LEAD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool pair_enabled() {
     static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
     return on;
@@ -390,10 +420,11 @@ static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32) {
 }
 
 struct WsLayout {
-    size_t sc, yp, yz, up, vp, img, img2, blk, soc, queue, scratch, total;
+    size_t sc, yp, yz, up, vp, img, img2, img3, blk, soc, queue, scratch, total;
     long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
     long img2_stride;                  // pair kernel's image (0 = none)
-    int max_blocks, img_L, img_NL, img2_L, img2_NL = 32;
+    long img3_stride;                  // ... and its lead image
+    int max_blocks, img_L, img_NL, img2_L, img2_NL = 32, lead = 0;
 };
 
 static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, int n_cells,
@@ -410,16 +441,15 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     // whose shape the scan kernel supports: the winners' fit then runs on the scan kernel)
     em_scan_layout(T, PP, QQ, &L.img_L, &L.img_NL, &L.img_stride);
     L.img = o; o = align256(o + sizeof(double) * (size_t)L.img_stride * n_series);
-    L.img2_stride = 0; L.img2_L = 0;
-    if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {      // room for either member's image
-        int l32 = 0, l16 = 0;
-        long s32 = 0, s16 = 0;
-        em_pair_layout(T, PP, QQ, 32, &l32, &s32);
-        em_pair_layout(T, PP, QQ, 16, &l16, &s16);
-        L.img2_stride = std::max(s32, s16);
-        L.img2_L = s32 ? l32 : l16;
+    // room for the pair family's images whatever runs in the end (the launch decides: member,
+    // chunk length, a closed-form lead): the largest 32-lane image, and u_t of a lead of up to T steps
+    L.img2_stride = 0; L.img2_L = 0; L.img3_stride = 0;
+    if (PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL) {
+        L.img2_stride = pair_image_doubles(32, PP, QQ, 32);
+        L.img3_stride = (long)(T + 32) * PP;
     }
     L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
+    L.img3 = o; o = align256(o + sizeof(double) * (size_t)L.img3_stride * n_series);
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
@@ -472,6 +502,28 @@ static bool scan_uses_queue(int T, int PP, int QQ, double tol) {
     return tol > 0.0 || em_scan_queue_only(T, PP, QQ);
 }
 
+// the tail [T - tail, T) AUTO sweeps when the first lead_steps steps of every series are missing
+// (0: no closed-form lead) -- the same rule as em_batch_device_impl
+static int lead_tail(int T, int PP, int QQ, int lead_steps) {
+    if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 2 || QQ > 4) return 0;
+    int tail = std::max(T - lead_steps, 80);
+    tail = (tail + 15) / 16 * 16;
+    if (tail > 256 || T - tail < 128) return 0;
+    return (em_pair_supported(tail, PP, QQ, 16) || em_pair_supported(tail, PP, QQ, 32)) ? tail : 0;
+}
+
+extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
+                                 char *buf, size_t len) {
+    if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
+        return -1;
+    const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
+    if (!tail) return ldsr_em_plan(T, p, q, niter, tol, algo, buf, len);
+    const int lpc = em_pair_supported(tail, PP, QQ, 16) ? 16 : 32;
+    if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0, buf, len, true);
+    return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
+}
+
 extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf,
                             size_t len) {
     if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
@@ -520,6 +572,9 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.img2_stride = L.img2_stride;
     pp.L2 = L.img2_L;
     pp.NL2 = L.img2_NL;
+    pp.lead = L.lead;
+    pp.img3 = (L.lead > 0 && L.img3_stride) ? (double *)(ws + L.img3) : nullptr;
+    pp.img3_stride = L.img3_stride;
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -533,7 +588,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 int *d_n_iter, int *d_status, double *d_liks, int liks_nanfill,
                                 void *d_workspace, size_t workspace_bytes,
                                 const int *abort_flag = nullptr, int dense_hint = -1,
-                                int *algo_used = nullptr) {
+                                int *algo_used = nullptr, int lead_hint = -1, int *lead_used = nullptr,
+                                int lead_force = 0) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -546,48 +602,65 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const bool was_auto = algo == LDSR_ALGO_AUTO;
     algo = resolve_algo(algo, T, PP, QQ);
     const int algo_layout = algo;       // what the workspace was sized and laid out for
-    // AUTO with early stopping: the pair kernel couples two cells per wave and sixteen per
-    // workgroup (= per CU), so widely different iteration counts cost it more than they cost the
-    // scan kernel's four-cell workgroups.  Measured (converged runs, tol = 1e-5): fully observed
-    // series (cells stop after 28..63 iterations) pair +8..12 %; masked series (4..176, cfg5 up
-    // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
-    // series known to be fully observed (the host-pointer entries look; dense_hint).
-    if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
-    // ... and only when its workgroups (one per CU: 16 cells at two cells per wave, 32 at four) fill
-    // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
-    // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
-    int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
-    if (was_auto && algo == LDSR_ALGO_PAIR) {
-        auto fills = [&](int lp) {
-            if (!em_pair_supported(T, PP, QQ, lp)) return false;
-            const int c = em_pair_cells_per_block(T, PP, QQ, lp);
-            long wgs = 0;
-            for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
-            return wgs * 8 >= 7 * (long)device_cu_count(device);
-        };
-        if (fills(16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
-        else if (fills(32)) lpc = 32;
-        else algo = LDSR_ALGO_SCAN;
+    auto fills = [&](int Te, int lp) {   // do the pair family's workgroups (one per CU) fill the device?
+        if (!em_pair_supported(Te, PP, QQ, lp)) return false;
+        const int c = em_pair_cells_per_block(Te, PP, QQ, lp);
+        long wgs = 0;
+        for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
+        return force_fill() || wgs * 8 >= 7 * (long)device_cu_count(device);
+    };
+    // A long all-missing lead common to every series (paleo-type data; lead_hint from the caller
+    // that has seen y): the pair family's LEAD form handles it in closed form and sweeps only the
+    // tail -- [T - tail, T) with tail a multiple of 16 of at most 256 steps (chunks of <= 16 steps).
+    int lead = 0, lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
+    if (was_auto && algo != LDSR_ALGO_SERIAL) {
+        const int tail = lead_tail(T, PP, QQ, lead_hint);
+        if (tail) {
+            if (fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            else if (fills(tail, 32)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
+        }
+    }
+    if (lead_force > 0 && (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD)) lead = lead_force;   // (a re-run of part of a batch)
+    if (lead_used) *lead_used = lead;
+    const int Te = T - lead;            // steps the sweeps of the pair family work on
+    if (!lead) {
+        // AUTO with early stopping: the pair kernel couples two cells per wave and sixteen per
+        // workgroup (= per CU), so widely different iteration counts cost it more than they cost the
+        // scan kernel's four-cell workgroups.  Measured (converged runs, tol = 1e-5): fully observed
+        // series (cells stop after 28..63 iterations) pair +8..12 %; masked series (4..176, cfg5 up
+        // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
+        // series known to be fully observed (the host-pointer entries look; dense_hint).
+        if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
+        // ... and only when its workgroups (one per CU: 16 cells at two cells per wave, 32 at four) fill
+        // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
+        // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
+        if (was_auto && algo == LDSR_ALGO_PAIR) {
+            if (fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+            else if (fills(T, 32)) lpc = 32;
+            else algo = em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
+        }
     }
     if (algo != LDSR_ALGO_SERIAL && algo != LDSR_ALGO_SCAN && algo != LDSR_ALGO_PAIR && algo != LDSR_ALGO_QUAD)
         return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
-    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(T, PP, QQ, 32))
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(Te, PP, QQ, 32))
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
-    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(T, PP, QQ, 16))
+    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
     const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;      // several cells per wave
     if (algo_used) *algo_used = algo;
-    const int cpb = cells_per_block(algo, T, PP, QQ, lpc);
+    const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
-    if (cpw) {       // the image of the member that runs (the room is the larger of the two)
+    if (cpw) {       // the image of the member that runs (the room is for the largest)
         long sz = 0;
-        em_pair_layout(T, PP, QQ, lpc, &L.img2_L, &sz);
+        em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz);
         L.img2_NL = lpc;
+        L.lead = lead;
     } else {
-        L.img2_stride = 0;       // no pair-family launch: series_prep skips the second image
+        L.img2_stride = 0;       // no pair-family launch: series_prep skips its images
+        L.img3_stride = 0;
     }
     if (workspace_bytes < L.total)
         return fail(LDSR_EINVAL, "workspace too small: need " + std::to_string(L.total) + " bytes");
@@ -643,6 +716,9 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.img_stride = L.img_stride;
     prm.img2 = L.img2_stride ? (const double *)(ws + L.img2) : nullptr;
     prm.img2_stride = L.img2_stride;
+    prm.lead = cpw ? lead : 0;
+    prm.img3 = (cpw && lead > 0) ? (const double *)(ws + L.img3) : nullptr;
+    prm.img3_stride = L.img3_stride;
     prm.fitX = prm.fitY = prm.fitV = prm.fitJ = prm.pen = nullptr;
     prm.lambda = 0.0;
     prm.stdlik = 1;
@@ -658,6 +734,13 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.scratch_stride = L.scratch_stride;
     int slot;
     HIPCHK(prof_begin(device, stream, &slot));
+    {
+        char nm[160];
+        if (cpw) em_pair_kernel_name(Te, PP, QQ, lpc, use_queue, nm, sizeof(nm), lead > 0);
+        else if (algo == LDSR_ALGO_SCAN) em_scan_kernel_name(T, PP, QQ, use_queue, false, nm, sizeof(nm));
+        else em_serial_kernel_name(T, PP, QQ, nm, sizeof(nm));
+        remember_kernel(device, nm);
+    }
     if (cpw)
         HIPCHK(launch_em_pair(prm, PP, QQ, lpc, n_blocks, use_queue, stream));
     else if (algo == LDSR_ALGO_SCAN)
@@ -666,6 +749,19 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
     HIPCHK(prof_end(stream, slot));
     return LDSR_OK;
+}
+
+extern "C" int ldsr_em_batch_device_lead(int device, void *stream_, int n_series, int T, int p, int q,
+                                         const double *d_y, const double *d_u, const double *d_v,
+                                         int shared_uv, const int *cell_offsets,
+                                         const double *d_theta0, int niter, double tol, int algo,
+                                         double *d_theta, double *d_lik, int *d_n_iter, int *d_status,
+                                         double *d_liks, void *d_workspace, size_t workspace_bytes,
+                                         int lead_steps) {
+    return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
+                                shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
+                                d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes, nullptr,
+                                -1, nullptr, lead_steps);
 }
 
 extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int T, int p, int q,
@@ -777,6 +873,8 @@ struct Slice {
     int device = 0, n_series = 0, T = 0, p = 0, q = 0, shared_uv = 0, niter = 0, algo = 0;
     int dense_hint = -1;     // 1: every y_t of every series is finite (AUTO's kernel choice with tol > 0)
     int algo_used = 0;       // the algorithm the batch launch resolved to
+    int lead_used = 0;       // ... and the closed-form lead it used
+    int lead_hint = -1;      // steps before the first observation of any series
     double tol = 0.0;
     const double *y = nullptr, *u = nullptr, *v = nullptr, *theta0 = nullptr;
     std::vector<int> off;
@@ -895,6 +993,14 @@ static int slice_run(Slice &S) {
         const size_t ny = (size_t)S.n_series * T;
         for (size_t i = 0; i < ny && all_obs; i++) all_obs = std::isfinite(S.y[i]);
         S.dense_hint = all_obs ? 1 : 0;
+        // all-missing lead common to every series (the pair family's closed form)
+        int lead = T;
+        for (int s = 0; s < S.n_series && lead > 0; s++) {
+            int t = 0;
+            while (t < lead && !std::isfinite(S.y[(size_t)s * T + t])) t++;
+            lead = std::min(lead, t);
+        }
+        S.lead_hint = lead;
     }
     if (S.u) memcpy(pin + (S.d_u - S.d_in), S.u, sizeof(double) * nuv * T * S.p);
     if (S.v) memcpy(pin + (S.d_v - S.d_in), S.v, sizeof(double) * nuv * T * S.q);
@@ -908,7 +1014,8 @@ static int slice_run(Slice &S) {
         S.shared_uv, S.off.data(), (const double *)(A->dev + S.d_th0), S.niter, S.tol, S.algo,
         (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
         (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
-        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint, &S.algo_used);
+        S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint, &S.algo_used,
+        S.lead_hint, &S.lead_used);
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
     if (S.fuse && S.trace_on_device) {
@@ -1034,7 +1141,8 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
             S.shared_uv, sel_off.data(), (const double *)(dw + W.theta0), niter, S.tol,
             S.algo_used ? S.algo_used : S.algo,       // the kernel of the batch run, whatever AUTO would pick for a few cells
             (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
-            (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb, nullptr, S.dense_hint);
+            (int *)(A->dev + S.d_st), (double *)(dw + W.liks), 1, ws, S.wsb, nullptr, S.dense_hint, nullptr, -1,
+            nullptr, S.lead_used);
         if (rc) return rc;
     }
     // the winners' fit: one smoother pass at theta_w on the prepared series

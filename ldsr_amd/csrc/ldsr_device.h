@@ -302,6 +302,9 @@ struct EmParams {
     long img_stride;         // doubles per series image
     const double *img2;      // pair kernel (em_pair_impl.h): [n_series] images in its 32-lane layout, or null
     long img2_stride;
+    int lead;                // pair kernel: all-missing first steps of every series handled in closed form (0 = none)
+    const double *img3;      // ... and their (whitened) u_t, [n_series][step of the lane][lane][PP]
+    long img3_stride;
     const SeriesConst *sc;   // [n_series]
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)

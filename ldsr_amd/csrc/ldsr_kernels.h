@@ -15,6 +15,9 @@ struct PrepParams {
     double *img2;             // pair kernel: second image per series (NL2 virtual lanes, chunk length L2), or null
     long img2_stride;
     int L2, NL2;
+    int lead;                 // pair kernel's LEAD form: img2 covers the tail [lead, T) only ...
+    double *img3;             // ... and img3 the (whitened) u_t of the lead, [step of the lane][NL2 lanes][PP], or null
+    long img3_stride;
     SeriesConst *sc;
     int *queue;               // [n_series] work-queue heads, reset to 0 here
 };
@@ -76,7 +79,7 @@ bool em_pair_supported(int T, int PP, int QQ, int lpc);
 int em_pair_cells_per_block(int T, int PP, int QQ, int lpc);
 void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles);
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue, hipStream_t stream);
-void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len);
+void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead = false);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);

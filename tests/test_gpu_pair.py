@@ -198,19 +198,36 @@ def test_auto_choice(eng):
     assert _plan_name(T, p, q, 1e-5)[1].startswith("em_scan_kernel")
     big = synth.make_init_packed(p, q, 4096, seed=2)
     small = big[:24].copy()
-    for mask, same_as in (("dense", PAIR), ("paleo", SCAN)):
-        y, u, v = _series(T, p, q, 4, mask)
-        a = eng.em_batch(y, u, v, big, niter=300, tol=1e-5)
-        b = eng.em_batch(y, u, v, big, niter=300, tol=1e-5, algo=same_as)
-        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["lik"], b["lik"]), mask
-        # tol == 0: the pair kernel whatever the mask ...
-        a = eng.em_batch(y, u, v, big, niter=12, tol=0.0)
-        b = eng.em_batch(y, u, v, big, niter=12, tol=0.0, algo=PAIR)
-        assert np.array_equal(a["theta"], b["theta"]), mask
-        # ... unless the launch is small
-        a = eng.em_batch(y, u, v, small, niter=12, tol=0.0)
-        b = eng.em_batch(y, u, v, small, niter=12, tol=0.0, algo=SCAN)
-        assert np.array_equal(a["theta"], b["theta"]), mask
+
+    def last_kernel():
+        from ldsr_amd import _lib
+        buf = C.create_string_buffer(160)
+        assert _lib.lib().ldsr_last_em_kernel(0, buf, 160) == 0
+        return buf.value.decode()
+
+    # fully observed: the pair kernel with and without early stopping (bit-identical to algo = PAIR)
+    y, u, v = _series(T, p, q, 4, "dense")
+    for niter, tol in ((300, 1e-5), (12, 0.0)):
+        a = eng.em_batch(y, u, v, big, niter=niter, tol=tol)
+        assert last_kernel() == "em_pair_kernel<1, 2, 32, 32, %s>" % ("true" if tol > 0 else "false")
+        b = eng.em_batch(y, u, v, big, niter=niter, tol=tol, algo=PAIR)
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["lik"], b["lik"]), tol
+    # ... unless the launch is small
+    a = eng.em_batch(y, u, v, small, niter=12, tol=0.0)
+    assert last_kernel().startswith("em_scan_kernel<1, 2, 16, 1,")
+    # a scattered mask with early stopping: the scan kernel (iteration counts spread too widely)
+    y, u, v = _series(T, p, q, 4, "holes")
+    a = eng.em_batch(y, u, v, big, niter=100, tol=1e-5)
+    assert last_kernel() == "em_scan_kernel<1, 2, 16, 1, true, false, false>"
+    # a paleo-type mask (900 unobserved steps, then the record): the closed-form lead on the
+    # four-cells-per-wave... here two-cells-per-wave kernel (4096 cells fill 16-cell workgroups only)
+    y, u, v = _series(T, p, q, 4, "paleo")
+    for niter, tol in ((300, 1e-5), (12, 0.0)):
+        a = eng.em_batch(y, u, v, big, niter=niter, tol=tol)
+        assert last_kernel() == "em_pair_kernel<1, 2, 4, 32, %s, true>" % ("true" if tol > 0 else "false")
+        b = eng.em_batch(y, u, v, big, niter=niter, tol=tol, algo=SCAN)
+        assert np.array_equal(a["n_iter"], b["n_iter"])
+        assert parity_close(a["theta"], b["theta"], 1e-8, 1e-11) and parity_close(a["lik"], b["lik"], 1e-9, 1e-12)
     # T <= 512: four cells per wave once 32-cell workgroups fill the device (8192 cells), two cells
     # per wave for 4096, the scan kernel for a few
     y, u, v = _series(400, p, q, 4, "dense")
