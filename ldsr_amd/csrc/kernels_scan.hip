@@ -128,7 +128,7 @@ void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles) {
 }
 void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead) {
     const PairPlan p = pair_plan(T, PP, QQ, lpc);
-    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s%s>", PP, QQ, p.L, lpc, queue ? "true" : "false", lead ? ", true" : "");
+    snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s, %s>", PP, QQ, p.L, lpc, queue ? "true" : "false", lead ? "true" : "false");
 }
 
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,

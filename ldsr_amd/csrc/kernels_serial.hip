@@ -199,6 +199,9 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
         if (u) ok = chol_small(sc.Tuu_inv, sc.Lu, sc.Lu_inv, p) && ok;
         if (v) ok = invert_small(sc.Svv_inv, inv_ws, q) && ok;
         if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p) && ok;
+        // a caller-supplied lead (ldsr_em_batch_device_lead) that is not all-missing in this series
+        // would silently drop observations: refuse the series like a singular one
+        if (prm.img3 && prm.lead > 0 && sc.n_obs > 0 && sc.t_first_obs < prm.lead) ok = false;
         sc.status = ok ? 0 : 2;
         for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
             double a = 0.0;

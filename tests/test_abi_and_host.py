@@ -85,14 +85,14 @@ def test_launch_plan_of_every_shape():
         a = L.ldsr_em_plan(T, p, q, 100, float(tol), algo, buf, 160)
         return a, buf.value.decode()
 
-    assert plan(1000, 1, 2) == (3, "em_pair_kernel<1, 2, 32, 32, false>")          # BASELINE config 2
-    assert plan(813, 1, 3) == (3, "em_pair_kernel<1, 4, 26, 32, false>")           # config 5
+    assert plan(1000, 1, 2) == (3, "em_pair_kernel<1, 2, 32, 32, false, false>")          # BASELINE config 2
+    assert plan(813, 1, 3) == (3, "em_pair_kernel<1, 4, 26, 32, false, false>")           # config 5
     assert plan(1000, 4, 8) == (2, "em_scan_kernel<4, 8, 16, 1, false, false, false>")   # config 3
     assert plan(2000, 1, 4) == (2, "em_scan_kernel<1, 4, 32, 1, false, false, false>")   # config 4
     assert plan(1000, 1, 2, 1e-5) == (2, "em_scan_kernel<1, 2, 16, 1, true, false, false>")
-    assert plan(1000, 1, 2, 1e-5, 3) == (3, "em_pair_kernel<1, 2, 32, 32, true>")
-    assert plan(85, 1, 2) == (4, "em_pair_kernel<1, 2, 6, 16, false>")
-    assert plan(213, 3, 3) == (4, "em_pair_kernel<4, 4, 14, 16, false>")           # the NP test slice
+    assert plan(1000, 1, 2, 1e-5, 3) == (3, "em_pair_kernel<1, 2, 32, 32, true, false>")
+    assert plan(85, 1, 2) == (4, "em_pair_kernel<1, 2, 6, 16, false, false>")
+    assert plan(213, 3, 3) == (4, "em_pair_kernel<4, 4, 14, 16, false, false>")           # the NP test slice
     assert plan(85, 7, 7)[1].startswith("em_scan_kernel<8, 8,")                     # the P1 known-answer case
     assert plan(4000, 2, 2)[1].startswith("em_scan_kernel<2, 2, 32, 2, true, true, false>")
     assert plan(9000, 1, 1)[0] == 1 and plan(500, 9, 1)[0] == 1                      # serial kernel

@@ -92,7 +92,7 @@ def test_lead_plan_and_limits(eng):
     for args in ((1000, 1, 2, 100), (1000, 1, 2, 600), (1000, 3, 2, 900), (1000, 1, 8, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
     assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
-    assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false>"
+    assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false, false>"
 
 
 def test_restart_grid_with_a_lead(eng, monkeypatch):
@@ -124,3 +124,34 @@ def test_results_do_not_depend_on_the_wave_partner(eng):
     a = eng.em_batch(y, u, v, th0, niter=40, tol=1e-5)
     b = eng.em_batch(y, u, v, th0[::-1].copy(), niter=40, tol=1e-5)
     assert np.array_equal(a["theta"], b["theta"][::-1]) and np.array_equal(a["n_iter"], b["n_iter"][::-1])
+
+
+def test_device_entry_refuses_a_lead_that_is_not_missing(eng):
+    """ldsr_em_batch_device_lead trusts its lead_steps argument for the launch plan; a series with
+    an observation inside the claimed lead ends with status 2 (NaN results) instead of a fit that
+    silently ignored data."""
+    import torch
+    from ldsr_amd import _lib, synth
+    L = _lib.lib()
+    T, p, q, n = 1000, 1, 2, 8192
+    y, u, v = synth.make_series(T, p, q, series_id=2)
+    y = y.copy(); y[:850] = np.nan
+    th0 = synth.make_init_packed(p, q, n, seed=1)
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in
+         (("y", y[None]), ("u", u.T), ("v", v.T), ("th0", th0))}
+    th = torch.empty_like(d["th0"]); lik = torch.empty(n, dtype=torch.float64, device=dev)
+    nit = torch.empty(n, dtype=torch.int32, device=dev); st = torch.empty(n, dtype=torch.int32, device=dev)
+    wsb = L.ldsr_em_workspace_bytes(1, T, p, q, n, 0)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) & ~255
+    off = (C.c_int * 2)(0, n)
+    stream = torch.cuda.current_stream(dev)
+    for lead, want in ((850, 0), (900, 2)):
+        _lib.check(L.ldsr_em_batch_device_lead(0, C.c_void_p(stream.cuda_stream), 1, T, p, q, d["y"].data_ptr(),
+                                               d["u"].data_ptr(), d["v"].data_ptr(), 0, off, d["th0"].data_ptr(),
+                                               10, 0.0, 0, th.data_ptr(), lik.data_ptr(), nit.data_ptr(),
+                                               st.data_ptr(), None, C.c_void_p(ws_ptr), wsb, lead))
+        torch.cuda.synchronize(dev)
+        assert _last_kernel().endswith(", true>")
+        assert np.all(st.cpu().numpy() == want), (lead, np.bincount(st.cpu().numpy()))

@@ -72,9 +72,9 @@ def test_every_chunk_length_matches_oracle(eng, T, mask):
     y, u, v = _series(T, p, q, 100 + T, mask)
     th0 = synth.make_init_packed(p, q, 21, seed=T)          # odd count: one half-wave idles
     # AUTO's plan (a launch that fills the device assumed): four cells per wave up to T = 512, two above
-    assert _plan_name(T, p, q, 0.0)[1] == "em_pair_kernel<1, 2, %d, %d, false>" % (
+    assert _plan_name(T, p, q, 0.0)[1] == "em_pair_kernel<1, 2, %d, %d, false, false>" % (
         (max(5, -(-T // 16)), 16) if T <= 512 else (-(-T // 32), 32))
-    assert _plan_name(T, p, q, 0.0, PAIR)[1] == "em_pair_kernel<1, 2, %d, 32, false>" % max(3, -(-T // 32))
+    assert _plan_name(T, p, q, 0.0, PAIR)[1] == "em_pair_kernel<1, 2, %d, 32, false, false>" % max(3, -(-T // 32))
     for niter, tol in ((25, 0.0), (300, 1e-5)):
         ref = _oracle(y, u.T[None], v.T[None], np.zeros(21), th0, niter, tol)
         for algo in (PAIR, QUAD) if T <= 512 else (PAIR,):
@@ -177,7 +177,7 @@ def test_config2_whole_batch_converged(eng):
     per-half work queue; AUTO must have picked the pair kernel."""
     import bench
     Y, U, V, shared, off, th0, n = bench.build_problem("cfg2", "dense", 1, 0)
-    assert _plan_name(1000, 1, 2, 1e-5, PAIR)[1] == "em_pair_kernel<1, 2, 32, 32, true>"
+    assert _plan_name(1000, 1, 2, 1e-5, PAIR)[1] == "em_pair_kernel<1, 2, 32, 32, true, false>"
     ref = _oracle(Y, U, V, np.zeros(n), th0, 1000, 1e-5)
     r = eng.em_batch(Y[0], U[0].T.copy(), V[0].T.copy(), th0, niter=1000, tol=1e-5)
     _check(r, ref, "cfg2")
@@ -209,7 +209,7 @@ def test_auto_choice(eng):
     y, u, v = _series(T, p, q, 4, "dense")
     for niter, tol in ((300, 1e-5), (12, 0.0)):
         a = eng.em_batch(y, u, v, big, niter=niter, tol=tol)
-        assert last_kernel() == "em_pair_kernel<1, 2, 32, 32, %s>" % ("true" if tol > 0 else "false")
+        assert last_kernel() == "em_pair_kernel<1, 2, 32, 32, %s, false>" % ("true" if tol > 0 else "false")
         b = eng.em_batch(y, u, v, big, niter=niter, tol=tol, algo=PAIR)
         assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["lik"], b["lik"]), tol
     # ... unless the launch is small

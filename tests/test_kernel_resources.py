@@ -36,11 +36,12 @@ def test_scan_kernel_register_budget():
 
 def test_pair_kernel_register_budget():
     """The two-cells-per-wave kernels of BASELINE configs 2 (T=1000: L=32) and 5 (T=813: L=26) and
-    the four-cells-per-wave kernel of a short series: two waves per SIMD and no scratch (the first
+    the four-cells-per-wave kernel of a short series, and the LEAD forms of configs 4 and 5: two waves per SIMD and no scratch (the first
     cut of the pair kernel spilled 73 VGPRs until the reverse composite moved into F2)."""
     import resource_usage
-    for tu, tmpl in (("em_pair_L32.hip", "<1, 2, 32, 32, false>"), ("em_pair_L32.hip", "<1, 2, 32, 32, true>"),
-                     ("em_pair_L26.hip", "<1, 4, 26, 32, false>"), ("em_quad_L13.hip", "<1, 2, 13, 16, false>")):
+    for tu, tmpl in (("em_pair_L32.hip", "<1, 2, 32, 32, false, false>"), ("em_pair_L32.hip", "<1, 2, 32, 32, true, false>"),
+                     ("em_pair_L26.hip", "<1, 4, 26, 32, false, false>"), ("em_quad_L13.hip", "<1, 2, 13, 16, false, false>"),
+                     ("em_quad_L13.hip", "<1, 4, 13, 16, false, true>"), ("em_quad_L6.hip", "<1, 4, 6, 16, false, true>")):
         rows = resource_usage.table(os.path.join(ROOT, "ldsr_amd", "csrc", tu), tmpl)
         assert len(rows) == 1, (tu, tmpl, [r[0] for r in rows])
         _, vgpr, agpr, vspill, scratch, occ, sgpr, sspill = rows[0]
