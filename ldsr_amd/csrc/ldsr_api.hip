@@ -509,7 +509,17 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     int tail = std::max(T - lead_steps, 80);
     tail = (tail + 15) / 16 * 16;
     if (tail > 256 || T - tail < 128) return 0;
-    return (em_pair_supported(tail, PP, QQ, 16) || em_pair_supported(tail, PP, QQ, 32)) ? tail : 0;
+    // the lead's u_t live in LDS behind the tail's image and the eight strips
+    auto fits = [&](int lp) {
+        int Lc = 0;
+        long img = 0;
+        em_pair_layout(tail, PP, QQ, lp, &Lc, &img);
+        if (!img) return false;
+        const size_t lds = ((size_t)img + 8 * (size_t)pair_strip_doubles(Lc) +
+                            (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
+        return lds <= 160 * 1024;
+    };
+    return (fits(16) && fits(32)) ? tail : 0;
 }
 
 extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,

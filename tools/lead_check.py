@@ -61,5 +61,7 @@ if __name__ == "__main__":
     allok &= run(813, 1, 3, 8192, 730, 30, 0.0, S=4)
     allok &= run(813, 2, 2, 8192, 700, 200, 1e-5, S=2)
     allok &= run(600, 1, 1, 8192, 400, 25, 0.0)
+    allok &= run(8000, 1, 2, 8192, 7800, 8, 0.0)          # a very long lead (scan kernel: four waves per cell)
+    allok &= run(4000, 2, 4, 8192, 3790, 60, 1e-5, holes=True)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)
