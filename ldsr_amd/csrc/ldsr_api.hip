@@ -505,7 +505,7 @@ static bool scan_uses_queue(int T, int PP, int QQ, double tol) {
 // the tail [T - tail, T) AUTO sweeps when the first lead_steps steps of every series are missing
 // (0: no closed-form lead) -- the same rule as em_batch_device_impl
 static int lead_tail(int T, int PP, int QQ, int lead_steps) {
-    if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 2 || QQ > 4) return 0;
+    if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 4 || QQ > 4) return 0;
     int tail = std::max(T - lead_steps, 80);
     tail = (tail + 15) / 16 * 16;
     if (tail > 256 || T - tail < 128) return 0;
@@ -519,7 +519,7 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
                             (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
         return lds <= 160 * 1024;
     };
-    return (fits(16) && fits(32)) ? tail : 0;
+    return ((PP > 2 || fits(16)) && fits(32)) ? tail : 0;      // (p = 3, 4: two cells per wave only)
 }
 
 extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
@@ -529,7 +529,7 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
     if (!tail) return ldsr_em_plan(T, p, q, niter, tol, algo, buf, len);
-    const int lpc = em_pair_supported(tail, PP, QQ, 16) ? 16 : 32;
+    const int lpc = (PP <= 2 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
     if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
 }
@@ -626,7 +626,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (was_auto && algo != LDSR_ALGO_SERIAL) {
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
-            if (fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            if (PP <= 2 && fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(tail, 32)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }

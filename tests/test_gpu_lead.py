@@ -67,6 +67,8 @@ def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
     (813, 2, 2, 2, 600, True, 5),
     (700, 1, 1, 1, 500, False, 0),
     (1500, 2, 4, 1, 1300, False, 0),
+    (813, 3, 3, 1, 760, False, 0),         # the bundled Nakhon Phanom shape: p = 3 pads to 4, two cells per wave
+    (1200, 4, 1, 2, 1000, True, 3),
 ])
 def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
     Y, U, V, off, th0 = _grid(T, p, q, S, lead, 8192 // S, 60 + T, holes, stagger)
@@ -89,7 +91,8 @@ def test_lead_plan_and_limits(eng):
     assert plan(1000, 1, 2, 900, 1e-5) == (4, "em_pair_kernel<1, 2, 7, 16, true, true>")
     assert plan(813, 1, 3, 723)[1] == "em_pair_kernel<1, 4, 6, 16, false, true>"           # config 5
     # no closed form: short leads, long tails, wide u, explicit algorithms -- the ordinary plan
-    for args in ((1000, 1, 2, 100), (1000, 1, 2, 600), (1000, 3, 2, 900), (1000, 1, 8, 900)):
+    assert plan(813, 3, 3, 760)[1] == "em_pair_kernel<4, 4, 3, 32, false, true>"           # p = 3,4: two cells per wave
+    for args in ((1000, 1, 2, 100), (1000, 1, 2, 600), (1000, 5, 2, 900), (1000, 1, 8, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
     assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
     assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false, false>"

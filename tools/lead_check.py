@@ -61,6 +61,9 @@ if __name__ == "__main__":
     allok &= run(813, 1, 3, 8192, 730, 30, 0.0, S=4)
     allok &= run(813, 2, 2, 8192, 700, 200, 1e-5, S=2)
     allok &= run(600, 1, 1, 8192, 400, 25, 0.0)
+    allok &= run(813, 3, 3, 8192, 760, 40, 0.0)           # the bundled Nakhon Phanom shape (46 of 813 observed)
+    allok &= run(813, 3, 3, 8192, 760, 300, 1e-5)
+    allok &= run(1200, 4, 1, 8192, 1000, 30, 0.0, holes=True)
     allok &= run(8000, 1, 2, 8192, 7800, 8, 0.0)          # a very long lead (scan kernel: four waves per cell)
     allok &= run(4000, 2, 4, 8192, 3790, 60, 1e-5, holes=True)
     print("ALL OK" if allok else "FAILURES")
