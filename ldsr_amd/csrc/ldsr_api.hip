@@ -508,7 +508,8 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 4 || QQ > 4) return 0;
     int tail = std::max(T - lead_steps, 80);
     tail = (tail + 15) / 16 * 16;
-    if (tail > 256 || T - tail < 128) return 0;
+    static const int max_tail = [] { const char *e = getenv("LDSR_LEAD_MAX_TAIL"); return e ? atoi(e) : 512; }();
+    if (tail > max_tail || tail > 512 || T - tail < 128) return 0;
     // the lead's u_t live in LDS behind the tail's image and the eight strips
     auto fits = [&](int lp) {
         int Lc = 0;
@@ -519,7 +520,8 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
                             (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
         return lds <= 160 * 1024;
     };
-    return ((PP > 2 || fits(16)) && fits(32)) ? tail : 0;      // (p = 3, 4: two cells per wave only)
+    // (p = 3, 4 and tails beyond 256 steps: two cells per wave only)
+    return ((PP > 2 || tail > 256 || fits(16)) && fits(32)) ? tail : 0;
 }
 
 extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
@@ -529,7 +531,7 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
     if (!tail) return ldsr_em_plan(T, p, q, niter, tol, algo, buf, len);
-    const int lpc = (PP <= 2 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
+    const int lpc = (PP <= 2 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
     if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
 }
@@ -621,12 +623,13 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     };
     // A long all-missing lead common to every series (paleo-type data; lead_hint from the caller
     // that has seen y): the pair family's LEAD form handles it in closed form and sweeps only the
-    // tail -- [T - tail, T) with tail a multiple of 16 of at most 256 steps (chunks of <= 16 steps).
+    // tail -- [T - tail, T) with tail a multiple of 16 of at most 512 steps (chunks of <= 16 steps:
+    // four cells per wave up to 256 steps, two beyond).
     int lead = 0, lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
     if (was_auto && algo != LDSR_ALGO_SERIAL) {
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
-            if (PP <= 2 && fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            if (PP <= 2 && tail <= 256 && fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(tail, 32)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }

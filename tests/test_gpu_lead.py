@@ -69,6 +69,9 @@ def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
     (1500, 2, 4, 1, 1300, False, 0),
     (813, 3, 3, 1, 760, False, 0),         # the bundled Nakhon Phanom shape: p = 3 pads to 4, two cells per wave
     (1200, 4, 1, 2, 1000, True, 3),
+    (1000, 1, 2, 1, 560, True, 0),         # tails of 257..512 steps: two cells per wave, chunks of <= 16 steps
+    (2000, 2, 4, 2, 1500, False, 6),
+    (1500, 3, 3, 1, 1100, True, 0),
 ])
 def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
     Y, U, V, off, th0 = _grid(T, p, q, S, lead, 8192 // S, 60 + T, holes, stagger)
@@ -90,9 +93,11 @@ def test_lead_plan_and_limits(eng):
     assert plan(2000, 1, 4, 1800) == (4, "em_pair_kernel<1, 4, 13, 16, false, true>")      # config 4
     assert plan(1000, 1, 2, 900, 1e-5) == (4, "em_pair_kernel<1, 2, 7, 16, true, true>")
     assert plan(813, 1, 3, 723)[1] == "em_pair_kernel<1, 4, 6, 16, false, true>"           # config 5
-    # no closed form: short leads, long tails, wide u, explicit algorithms -- the ordinary plan
+    # no closed form: short leads, tails beyond 512 steps, wide u, explicit algorithms -- the ordinary plan
     assert plan(813, 3, 3, 760)[1] == "em_pair_kernel<4, 4, 3, 32, false, true>"           # p = 3,4: two cells per wave
-    for args in ((1000, 1, 2, 100), (1000, 1, 2, 600), (1000, 5, 2, 900), (1000, 1, 8, 900)):
+    assert plan(1000, 1, 2, 600)[1] == "em_pair_kernel<1, 2, 13, 32, false, true>"         # tail of 400 steps
+    assert plan(2000, 1, 4, 1500, 1e-5) == (3, "em_pair_kernel<1, 4, 16, 32, true, true>")
+    for args in ((1000, 1, 2, 100), (1000, 1, 2, 480), (1000, 5, 2, 900), (1000, 1, 8, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
     assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
     assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false, false>"

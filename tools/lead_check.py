@@ -64,6 +64,9 @@ if __name__ == "__main__":
     allok &= run(813, 3, 3, 8192, 760, 40, 0.0)           # the bundled Nakhon Phanom shape (46 of 813 observed)
     allok &= run(813, 3, 3, 8192, 760, 300, 1e-5)
     allok &= run(1200, 4, 1, 8192, 1000, 30, 0.0, holes=True)
+    allok &= run(1000, 1, 2, 8192, 520, 300, 1e-5, holes=True)   # tails of 257..512 steps
+    allok &= run(2000, 1, 4, 8192, 1500, 30, 0.0, S=3)
+    allok &= run(4000, 2, 2, 8192, 3500, 200, 1e-5)
     allok &= run(8000, 1, 2, 8192, 7800, 8, 0.0)          # a very long lead (scan kernel: four waves per cell)
     allok &= run(4000, 2, 4, 8192, 3790, 60, 1e-5, holes=True)
     print("ALL OK" if allok else "FAILURES")
