@@ -119,8 +119,27 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
     return p;
 }
 
+// Waves per workgroup of the launch: a CU holds eight waves of these kernels (256 VGPRs each), as
+// one workgroup of eight or -- where the LDS has room for two images and two sets of strips (and
+// two copies of a lead's u_t) -- as two workgroups of four.  The finer grain fills the last round
+// of a launch better: config 4 (10 240 cells = 320 eight-wave workgroups on 256 CUs: two rounds,
+// the second on a quarter of the device) 4.56 -> 3.45 ms, config 5 (768 = three full rounds)
+// 3.42 -> 3.29 ms; config 2's image allows one workgroup per CU only.  LDSR_PAIR_WPB=8 keeps
+// eight (A/B hook).
+int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
+    const PairPlan p = pair_plan(T, PP, QQ, lpc);
+    if (!p.ok) return 0;
+    static const int wpb_env = [] { const char *e = getenv("LDSR_PAIR_WPB"); return e ? atoi(e) : 0; }();
+    if (wpb_env == 8) return 8;
+    const int w = wpb_env == 2 ? 2 : 4;
+    const size_t lds = ((size_t)pair_image_doubles(p.L, PP, QQ, lpc) + (size_t)w * pair_strip_doubles(p.L) +
+                        (lead > 0 ? (size_t)pair_lead_doubles(lead, lpc, PP) : 0)) * sizeof(double);
+    // (the runtime keeps some LDS per workgroup for itself: leave 1 KiB per workgroup free)
+    return (8 / w) * (lds + 1024) <= kLdsBytes ? w : 8;
+}
+
 bool em_pair_supported(int T, int PP, int QQ, int lpc) { return pair_plan(T, PP, QQ, lpc).ok; }
-int em_pair_cells_per_block(int T, int PP, int QQ, int lpc) { return (64 / lpc) * pair_plan(T, PP, QQ, lpc).wpb; }
+int em_pair_cells_per_block(int T, int PP, int QQ, int lpc, int lead) { return (64 / lpc) * em_pair_waves_per_block(T, PP, QQ, lpc, lead); }
 void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles) {
     const PairPlan p = pair_plan(T, PP, QQ, lpc);
     *L = p.L;
@@ -133,8 +152,9 @@ void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, 
 
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,
                           hipStream_t stream) {
-    const PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc);     // (LEAD form: the tail's plan)
+    PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc);     // (LEAD form: the tail's plan)
     if (!p.ok || !prm.img2 || (prm.lead > 0 && !prm.img3)) return hipErrorInvalidValue;
+    p.wpb = em_pair_waves_per_block(prm.T - prm.lead, PP, QQ, lpc, prm.lead);
 #define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \
                                              : launch_em_pair_L<Lv, 16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
     switch (p.L) {

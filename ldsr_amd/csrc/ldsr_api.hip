@@ -410,10 +410,10 @@ static int resolve_algo(int algo, int T, int PP, int QQ) {
 
 // cells per workgroup of the EM launch (the workspace's block table is sized for the scan
 // kernel's value, the smallest of them, whenever its image is built)
-static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32) {
+static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32, int lead = 0) {
     if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
         if (algo == LDSR_ALGO_QUAD) lpc = 16;
-        const int c = em_pair_cells_per_block(T, PP, QQ, lpc);
+        const int c = em_pair_cells_per_block(T, PP, QQ, lpc, lead);
         return c > 0 ? c : 16;
     }
     return algo == LDSR_ALGO_SCAN ? em_scan_cells_per_block(T, PP, QQ) : 64;
@@ -451,6 +451,7 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
     L.img3 = o; o = align256(o + sizeof(double) * (size_t)L.img3_stride * n_series);
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
+    if (PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 4);    // the pair family's smallest workgroup
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
@@ -616,7 +617,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const int algo_layout = algo;       // what the workspace was sized and laid out for
     auto fills = [&](int Te, int lp) {   // do the pair family's workgroups (one per CU) fill the device?
         if (!em_pair_supported(Te, PP, QQ, lp)) return false;
-        const int c = em_pair_cells_per_block(Te, PP, QQ, lp);
+        const int c = (64 / lp) * 8;          // a CU's eight waves
         long wgs = 0;
         for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
         return force_fill() || wgs * 8 >= 7 * (long)device_cu_count(device);
@@ -663,7 +664,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
     const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;      // several cells per wave
     if (algo_used) *algo_used = algo;
-    const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc);
+    const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
     if (cpw) {       // the image of the member that runs (the room is for the largest)
