@@ -505,6 +505,12 @@ static bool scan_uses_queue(int T, int PP, int QQ, double tol) {
 
 // the tail [T - tail, T) AUTO sweeps when the first lead_steps steps of every series are missing
 // (0: no closed-form lead) -- the same rule as em_batch_device_impl
+// early stopping on series that may have missing steps: does the two-cells-per-wave kernel still
+// beat the scan kernel?  (measured: only in four-wave workgroups with chunks of <= 13 steps)
+static bool pair_pays_with_early_stopping(int T, int PP, int QQ) {
+    return T <= 416 && em_pair_waves_per_block(T, PP, QQ, 32, 0) == 4;
+}
+
 static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 4 || QQ > 4) return 0;
     int tail = std::max(T - lead_steps, 80);
@@ -544,16 +550,17 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const bool was_auto = algo == LDSR_ALGO_AUTO;
     algo = resolve_algo(algo, T, PP, QQ);
-    // what ldsr_em_batch_device runs (the host-pointer entries additionally take the pair kernel
-    // with tol > 0 when every series is fully observed)
-    if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0) algo = LDSR_ALGO_SCAN;
+    // what ldsr_em_batch_device runs (the host-pointer entries additionally take the pair / quad
+    // kernels with tol > 0 when every series is fully observed)
+    const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0;
+    if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
         if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
     } else if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
         // AUTO (a launch that fills the device assumed): four cells per wave where they fit, else two
         int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
-        if (was_auto && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+        if (was_auto && !masked_conv && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
         if (!em_pair_supported(T, PP, QQ, lpc)) return -1;
         if (buf && len) em_pair_kernel_name(T, PP, QQ, lpc, tol > 0.0, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
@@ -644,12 +651,16 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // series (cells stop after 28..63 iterations) pair +8..12 %; masked series (4..176, cfg5 up
         // to 745 iterations) pair -2..-24 %.  So with tol > 0 AUTO takes the pair kernel only for
         // series known to be fully observed (the host-pointer entries look; dense_hint).
-        if (was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1) algo = LDSR_ALGO_SCAN;
+        // (Short series are the exception: in the two-cells-per-wave kernel's four-wave workgroups --
+        // chunks of <= 13 steps -- the coupling costs less than the shared per-wave work saves:
+        // T = 300 (2,2) +34 %, T = 400 (1,2) +11..33 %; from T = 500 on the scan kernel wins by 5..24 %.)
+        const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1;
+        if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
         // ... and only when its workgroups (one per CU: 16 cells at two cells per wave, 32 at four) fill
         // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
         // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
         if (was_auto && algo == LDSR_ALGO_PAIR) {
-            if (fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+            if (!masked_conv && fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(T, 32)) lpc = 32;
             else algo = em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
         }
