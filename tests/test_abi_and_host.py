@@ -91,6 +91,10 @@ def test_launch_plan_of_every_shape():
     assert plan(2000, 1, 4) == (2, "em_scan_kernel<1, 4, 32, 1, false, false, false>")   # config 4
     assert plan(1000, 1, 2, 1e-5) == (2, "em_scan_kernel<1, 2, 16, 1, true, false, false>")
     assert plan(1000, 1, 2, 1e-5, 3) == (3, "em_pair_kernel<1, 2, 32, 32, true, false>")
+    # ... except for short series (four-wave workgroups, chunks of <= 13 steps): two cells per wave
+    assert plan(400, 1, 2, 1e-5) == (3, "em_pair_kernel<1, 2, 13, 32, true, false>")
+    assert plan(120, 4, 4, 1e-5) == (3, "em_pair_kernel<4, 4, 4, 32, true, false>")
+    assert plan(417, 1, 2, 1e-5)[0] == 2 and plan(500, 1, 4, 1e-5)[0] == 2
     assert plan(85, 1, 2) == (4, "em_pair_kernel<1, 2, 6, 16, false, false>")
     assert plan(213, 3, 3) == (4, "em_pair_kernel<4, 4, 14, 16, false, false>")           # the NP test slice
     assert plan(85, 7, 7)[1].startswith("em_scan_kernel<8, 8,")                     # the P1 known-answer case
