@@ -622,12 +622,24 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const bool was_auto = algo == LDSR_ALGO_AUTO;
     algo = resolve_algo(algo, T, PP, QQ);
     const int algo_layout = algo;       // what the workspace was sized and laid out for
-    auto fills = [&](int Te, int lp) {   // do the pair family's workgroups (one per CU) fill the device?
+    // Is the launch large enough for the pair family to pay?  Counted in CUs' worth of cells (eight
+    // waves).  Eight-wave workgroups (long chunks, and every LEAD form: one workgroup per CU, and a
+    // lone wave per SIMD is slow on their rolled lead loops): >= 7/8 of the CUs.  Four-wave
+    // workgroups (short series, two per CU): the shared per-wave work pays much earlier --
+    // same box, T = 400 (1,2) / 200 (2,2) / 300 (1,4), scan -> pair -> quad in ms: 1024 cells
+    // 0.47 -> 0.39 -> 0.54, 2048 0.50 -> 0.42 -> 0.57, 3072 0.74 -> 0.62 -> 0.59, 4096 0.94 -> 0.68 ->
+    // 0.62 (tools/fill_ab.sh) -- two cells per wave from 1/4 of the CUs (1024 cells), four from 3/8
+    // (3072 cells).
+    auto fills = [&](int Te, int lp, bool lead_form = false) {
         if (!em_pair_supported(Te, PP, QQ, lp)) return false;
         const int c = (64 / lp) * 8;          // a CU's eight waves
         long wgs = 0;
         for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
-        return force_fill() || wgs * 8 >= 7 * (long)device_cu_count(device);
+        const long cus = device_cu_count(device);
+        if (force_fill()) return true;
+        if (!lead_form && em_pair_waves_per_block(Te, PP, QQ, lp, 0) == 4)
+            return wgs * 8 >= (lp == 16 ? 3 : 2) * cus;
+        return wgs * 8 >= 7 * cus;
     };
     // A long all-missing lead common to every series (paleo-type data; lead_hint from the caller
     // that has seen y): the pair family's LEAD form handles it in closed form and sweeps only the
@@ -637,8 +649,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (was_auto && algo != LDSR_ALGO_SERIAL) {
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
-            if (PP <= 2 && tail <= 256 && fills(tail, 16)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
-            else if (fills(tail, 32)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
+            if (PP <= 2 && tail <= 256 && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            else if (fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }
     if (lead_force > 0 && (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD)) lead = lead_force;   // (a re-run of part of a batch)

@@ -188,7 +188,8 @@ def test_config2_whole_batch_converged(eng):
 
 def test_auto_choice(eng):
     """AUTO takes the pair kernel only for launches whose sixteen-cell workgroups fill the device
-    (below ~3600 cells the scan kernel's four-cell workgroups spread over more CUs), and with
+    (T = 1000: below ~3600 cells the scan kernel's four-cell workgroups spread over more CUs; short
+    series, whose four-wave workgroups sit two per CU, from 1024 cells), and with
     tol > 0 only when every series is fully observed (iteration counts of masked series spread too
     widely for two cells per wave; the device entry / ldsr_em_plan cannot look at y and stay on
     the scan kernel)."""
@@ -228,11 +229,11 @@ def test_auto_choice(eng):
         b = eng.em_batch(y, u, v, big, niter=niter, tol=tol, algo=SCAN)
         assert np.array_equal(a["n_iter"], b["n_iter"])
         assert parity_close(a["theta"], b["theta"], 1e-8, 1e-11) and parity_close(a["lik"], b["lik"], 1e-9, 1e-12)
-    # T <= 512: four cells per wave once 32-cell workgroups fill the device (8192 cells), two cells
-    # per wave for 4096, the scan kernel for a few
+    # short series (four-wave workgroups, two per CU): four cells per wave from 3072 cells, two
+    # from 1024, the scan kernel for a few
     y, u, v = _series(400, p, q, 4, "dense")
     big8 = synth.make_init_packed(p, q, 8192, seed=3)
-    for n, same_as in ((8192, QUAD), (4096, PAIR), (24, SCAN)):
+    for n, same_as in ((8192, QUAD), (4096, QUAD), (3000, PAIR), (1024, PAIR), (1000, SCAN), (24, SCAN)):
         a = eng.em_batch(y, u, v, big8[:n], niter=8, tol=0.0)
         b = eng.em_batch(y, u, v, big8[:n], niter=8, tol=0.0, algo=same_as)
         assert np.array_equal(a["theta"], b["theta"]), n
