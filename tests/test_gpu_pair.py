@@ -172,6 +172,36 @@ def test_cells_do_not_depend_on_their_partner_or_on_the_cut(eng):
         assert np.array_equal(a["theta"][5], c["theta"][0]) and a["lik"][5] == c["lik"][0]
 
 
+def test_results_do_not_depend_on_the_workgroup_size(eng, tmp_path):
+    """Two four-wave workgroups per CU (the default where the LDS allows) against one of eight
+    (LDSR_PAIR_WPB=8, read once per process -> a child process): bit-identical, static and queue."""
+    import os
+    import subprocess
+    import sys
+    from ldsr_amd import synth
+    T, p, q = 300, 2, 2
+    y, u, v = _series(T, p, q, 21, "holes")
+    th0 = synth.make_init_packed(p, q, 300, seed=5)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.savez(tmp_path / "in.npz", y=y, u=u, v=v, th0=th0)
+    code = ("import sys, numpy as np; sys.path.insert(0, @ROOT@); import ldsr_amd; d = np.load(@IN@); out = {}\n"
+            "for algo in (3, 4):\n"
+            "    for tol in (0.0, 1e-5):\n"
+            "        r = ldsr_amd.em_batch(d['y'], d['u'], d['v'], d['th0'], niter=60, tol=tol, algo=algo)\n"
+            "        out['t%d_%g' % (algo, tol)] = r['theta']; out['n%d_%g' % (algo, tol)] = r['n_iter']\n"
+            "np.savez(@OUT@, **out)\n")
+    code = code.replace("@ROOT@", repr(root)).replace("@IN@", repr(str(tmp_path / "in.npz"))).replace(
+        "@OUT@", repr(str(tmp_path / "out8.npz")))
+    env = dict(os.environ, LDSR_PAIR_WPB="8")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    ref = np.load(tmp_path / "out8.npz")
+    for algo in (PAIR, QUAD):
+        for tol in (0.0, 1e-5):
+            r = eng.em_batch(y, u, v, th0, niter=60, tol=tol, algo=algo)
+            assert np.array_equal(r["theta"], ref["t%d_%g" % (algo, tol)]), (algo, tol)
+            assert np.array_equal(r["n_iter"], ref["n%d_%g" % (algo, tol)]), (algo, tol)
+
+
 def test_config2_whole_batch_converged(eng):
     """BASELINE config 2 whole (4096 restarts, T=1000, p=1, q=2, niter=1000, tol=1e-5) through the
     per-half work queue; AUTO must have picked the pair kernel."""
