@@ -623,8 +623,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     algo = resolve_algo(algo, T, PP, QQ);
     const int algo_layout = algo;       // what the workspace was sized and laid out for
     // Is the launch large enough for the pair family to pay?  Counted in CUs' worth of cells (eight
-    // waves).  Eight-wave workgroups (long chunks, and every LEAD form: one workgroup per CU, and a
-    // lone wave per SIMD is slow on their rolled lead loops): >= 7/8 of the CUs.  Four-wave
+    // waves).  Eight-wave workgroups (long chunks): >= 7/8 of the CUs.  Four-wave
     // workgroups (short series, two per CU): the shared per-wave work pays much earlier --
     // same box, T = 400 (1,2) / 200 (2,2) / 300 (1,4), scan -> pair -> quad in ms: 1024 cells
     // 0.47 -> 0.39 -> 0.54, 2048 0.50 -> 0.42 -> 0.57, 3072 0.74 -> 0.62 -> 0.59, 4096 0.94 -> 0.68 ->
@@ -639,6 +638,12 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         if (force_fill()) return true;
         if (!lead_form && em_pair_waves_per_block(Te, PP, QQ, lp, 0) == 4)
             return wgs * 8 >= (lp == 16 ? 3 : 2) * cus;
+        // the closed-form lead skips most of the work, so it pays from ~1536 cells (same box, scan ->
+        // LEAD in ms, tools/lead_fill_ab.sh: T = 2000 (1,4) 1536 cells 1.94 -> 1.40, 3072 3.79 -> 1.47;
+        // T = 4000 (2,2) 1536 cells 8.27 -> 2.47; T = 813 (3,3) 1536 0.92 -> 0.85, 3072 1.42 -> 1.27);
+        // with early stopping only for long leads (2048 cells: T = 2000 2.81 -> 2.23, T = 813 2.85 -> 3.09)
+        if (lead_form && (tol == 0.0 || lead_hint >= 1024))
+            return wgs * (lp == 16 ? 16 : 8) >= 3 * cus;
         return wgs * 8 >= 7 * cus;
     };
     // A long all-missing lead common to every series (paleo-type data; lead_hint from the caller

@@ -250,12 +250,14 @@ def test_auto_choice(eng):
     y, u, v = _series(T, p, q, 4, "holes")
     a = eng.em_batch(y, u, v, big, niter=100, tol=1e-5)
     assert last_kernel() == "em_scan_kernel<1, 2, 16, 1, true, false, false>"
-    # a paleo-type mask (900 unobserved steps, then the record): the closed-form lead on the
-    # four-cells-per-wave... here two-cells-per-wave kernel (4096 cells fill 16-cell workgroups only)
+    # a paleo-type mask (900 unobserved steps, then the record): the closed-form lead -- four cells
+    # per wave from ~1536 cells; with early stopping (and a lead below 1024 steps) only when the
+    # launch fills the device: 4096 cells fill the two-cells-per-wave kernel's workgroups only
     y, u, v = _series(T, p, q, 4, "paleo")
     for niter, tol in ((300, 1e-5), (12, 0.0)):
         a = eng.em_batch(y, u, v, big, niter=niter, tol=tol)
-        assert last_kernel() == "em_pair_kernel<1, 2, 4, 32, %s, true>" % ("true" if tol > 0 else "false")
+        assert last_kernel() == ("em_pair_kernel<1, 2, 4, 32, true, true>" if tol > 0 else
+                                 "em_pair_kernel<1, 2, 7, 16, false, true>")
         b = eng.em_batch(y, u, v, big, niter=niter, tol=tol, algo=SCAN)
         assert np.array_equal(a["n_iter"], b["n_iter"])
         assert parity_close(a["theta"], b["theta"], 1e-8, 1e-11) and parity_close(a["lik"], b["lik"], 1e-9, 1e-12)
