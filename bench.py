@@ -247,6 +247,8 @@ class Job:
         fin = np.isfinite(Y)
         self.lead = int(min((np.argmax(r) if r.any() else Y.shape[1]) for r in fin)) if os.environ.get(
             "LDSR_BENCH_NO_LEAD") is None else 0
+        if fin.all() and os.environ.get("LDSR_BENCH_NO_LEAD") is None:
+            self.lead = -1         # every y_t observed (ldsr_hip.h: AUTO keeps the pair family with tol > 0)
 
         def step():
             _lib.check(L.ldsr_em_batch_device_lead(

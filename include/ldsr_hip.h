@@ -177,7 +177,10 @@ int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf
 /* The same two with one more piece of knowledge about the data: the first lead_steps time steps of
  * EVERY series are missing (paleo-type series: centuries before the instrumental period; 0 = none
  * or unknown).  LDSR_ALGO_AUTO then handles that lead in closed form and sweeps only the tail
- * (em_pair_impl.h, LEAD).  The host-pointer entries find the lead themselves. */
+ * (em_pair_impl.h, LEAD).  lead_steps = -1 says the opposite: every y_t of every series is
+ * observed -- AUTO then keeps the pair / quad kernels with tol > 0 as the host-pointer entries do
+ * for such series (a wrong claim costs speed, not correctness: the kernels look at the mask
+ * themselves).  The host-pointer entries find both facts in y. */
 int ldsr_em_batch_device_lead(int device, void *stream, int n_series, int T, int p, int q,
                               const double *d_y, const double *d_u, const double *d_v,
                               int shared_uv, const int *cell_offsets, const double *d_theta0,

@@ -531,13 +531,16 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     return ((PP > 2 || tail > 256 || fits(16)) && fits(32)) ? tail : 0;
 }
 
+static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len,
+                        bool fully_observed);
+
 extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
                                  char *buf, size_t len) {
     if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
         return -1;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
-    if (!tail) return ldsr_em_plan(T, p, q, niter, tol, algo, buf, len);
+    if (!tail) return em_plan_impl(T, p, q, niter, tol, algo, buf, len, lead_steps < 0);
     const int lpc = (PP <= 2 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
     if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
@@ -545,6 +548,11 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
 
 extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf,
                             size_t len) {
+    return em_plan_impl(T, p, q, niter, tol, algo, buf, len, false);
+}
+
+static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len,
+                        bool fully_observed) {
     if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ || niter < 2 || !(tol >= 0.0))
         return -1;
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
@@ -552,7 +560,7 @@ extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo
     algo = resolve_algo(algo, T, PP, QQ);
     // what ldsr_em_batch_device runs (the host-pointer entries additionally take the pair / quad
     // kernels with tol > 0 when every series is fully observed)
-    const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0;
+    const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && !fully_observed;
     if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
@@ -803,7 +811,7 @@ extern "C" int ldsr_em_batch_device_lead(int device, void *stream_, int n_series
     return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
                                 shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
                                 d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes, nullptr,
-                                -1, nullptr, lead_steps);
+                                lead_steps < 0 ? 1 : -1, nullptr, lead_steps < 0 ? 0 : lead_steps);
 }
 
 extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int T, int p, int q,

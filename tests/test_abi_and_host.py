@@ -95,6 +95,11 @@ def test_launch_plan_of_every_shape():
     assert plan(400, 1, 2, 1e-5) == (3, "em_pair_kernel<1, 2, 13, 32, true, false>")
     assert plan(120, 4, 4, 1e-5) == (3, "em_pair_kernel<4, 4, 4, 32, true, false>")
     assert plan(417, 1, 2, 1e-5)[0] == 2 and plan(500, 1, 4, 1e-5)[0] == 2
+    # ... and when the caller of the device entry says every y_t is observed (lead_steps = -1)
+    buf = C.create_string_buffer(160)
+    assert L.ldsr_em_plan_lead(1000, 1, 2, 100, 1e-5, 0, -1, buf, 160) == 3
+    assert buf.value.decode() == "em_pair_kernel<1, 2, 32, 32, true, false>"
+    assert L.ldsr_em_plan_lead(1000, 1, 2, 100, 1e-5, 0, 0, buf, 160) == 2
     assert plan(85, 1, 2) == (4, "em_pair_kernel<1, 2, 6, 16, false, false>")
     assert plan(213, 3, 3) == (4, "em_pair_kernel<4, 4, 14, 16, false, false>")           # the NP test slice
     assert plan(85, 7, 7)[1].startswith("em_scan_kernel<8, 8,")                     # the P1 known-answer case

@@ -163,3 +163,42 @@ def test_device_entry_refuses_a_lead_that_is_not_missing(eng):
         torch.cuda.synchronize(dev)
         assert _last_kernel().endswith(", true>")
         assert np.all(st.cpu().numpy() == want), (lead, np.bincount(st.cpu().numpy()))
+
+
+def test_device_entry_with_the_fully_observed_hint(eng):
+    """lead_steps = -1 (every y_t observed): the device entry keeps the pair kernel with tol > 0,
+    results identical to the host-pointer entry (which finds that in y); a wrong claim only costs
+    speed -- a masked series gives the scan kernel's numbers to 1e-9."""
+    import torch
+    from ldsr_amd import _lib, synth
+    L = _lib.lib()
+    T, p, q, n = 1000, 1, 2, 4096
+    for mask in ("dense", "holes"):
+        y, u, v = synth.make_series(T, p, q, series_id=77)
+        y = y.copy()
+        if mask == "holes":
+            y[100:130] = np.nan
+        th0 = synth.make_init_packed(p, q, n, seed=8)
+        ref = eng.em_batch(y, u, v, th0, niter=200, tol=1e-5, algo=3 if mask == "dense" else 2)
+        dev = torch.device("cuda:0")
+        P = 6 + p + q
+        d_y = torch.tensor(y, device=dev); d_u = torch.tensor(u.T.copy(), device=dev); d_v = torch.tensor(v.T.copy(), device=dev)
+        d_th0 = torch.tensor(th0, device=dev)
+        d_th = torch.empty((n, P), dtype=torch.float64, device=dev); d_lik = torch.empty(n, dtype=torch.float64, device=dev)
+        d_nit = torch.empty(n, dtype=torch.int32, device=dev); d_st = torch.empty(n, dtype=torch.int32, device=dev)
+        wsb = L.ldsr_em_workspace_bytes(1, T, p, q, n, 0)
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+        wp = (ws.data_ptr() + 255) & ~255
+        off = (C.c_int * 2)(0, n)
+        stream = torch.cuda.current_stream()
+        _lib.check(L.ldsr_em_batch_device_lead(0, C.c_void_p(stream.cuda_stream), 1, T, p, q, d_y.data_ptr(),
+                                               d_u.data_ptr(), d_v.data_ptr(), 1, off, d_th0.data_ptr(), 200, 1e-5, 0,
+                                               d_th.data_ptr(), d_lik.data_ptr(), d_nit.data_ptr(), d_st.data_ptr(), None,
+                                               C.c_void_p(wp), wsb, -1))
+        torch.cuda.synchronize()
+        assert _last_kernel() == "em_pair_kernel<1, 2, 32, 32, true, false>"
+        assert np.array_equal(d_nit.cpu().numpy(), ref["n_iter"])
+        if mask == "dense":
+            assert np.array_equal(d_th.cpu().numpy(), ref["theta"])
+        else:
+            assert parity_close(d_th.cpu().numpy(), ref["theta"], 1e-9, 1e-12)
