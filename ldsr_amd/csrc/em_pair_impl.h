@@ -38,12 +38,31 @@ __host__ __device__ constexpr long pair_image_doubles(int L, int PP, int QQ, int
 // h in a register)
 __host__ __device__ constexpr long pair_strip_doubles(int L) { return (long)64 * (L - 1); }
 
+// STEADY form (fully observed series, two cells per wave): the first L-1 steps of a series -- the
+// chunk of lane 0 -- are also kept one step per lane (`tri`, [pair][lane][2]) for the transient
+// block of em_pair_body
+__host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32) {
+    return (long)LPC * 2 * scan_pairs(PP, QQ);
+}
+#ifndef LDSR_STEADY            // 0: every dense cell takes the generic sweeps (A/B builds)
+#define LDSR_STEADY 1
+#endif
+#ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
+#define LDSR_STEADY_MIN_L 24
+#endif
+__host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
+    return LDSR_STEADY && LPC == 32 && L >= LDSR_STEADY_MIN_L &&
+           (pair_image_doubles(L, PP, QQ, LPC) + 8 * pair_strip_doubles(L) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
+}
+
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
-template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD>
+template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD, bool STEADY = false>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
-                                             const double *lu, int s, int c0, int nc, int lane, int wave) {
+                                             const double *lu, const double *tri, int s, int c0, int nc, int lane,
+                                             int wave) {
     static_assert(!(LEAD && DENSE), "a lead of missing steps and a fully observed series exclude each other");
+    static_assert(!STEADY || (DENSE && LPC == 32), "the steady sweeps: fully observed series, two cells per wave");
     constexpr int KP = scan_pairs(PP, QQ);
     static_assert(LPC == 32 || LPC == 16, "two or four cells per wave");
     constexpr int CPW = 64 / LPC;                         // cells per wave
@@ -215,252 +234,525 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             c_first = shfl_d(c_first, hbase);       // c_0 (lane 0 of the cell)
         }
 
-        // ------------------------------------------------ F1: compose this lane's step matrices;
-        // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
-        PMat M;
-        M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
-        if constexpr (DENSE) {
-            // Every step has the same 2x2 block Bm = [[alpha, Q],[C2R, 1]]: the chunk's block is a
-            // power of it (binary exponentiation) and only the third row needs the per-step
-            // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
-            // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
-            // power of two c = 2^-k with max(alpha, 1) c in [0.5, 1) (projective coordinates are
-            // scale free; alpha^31 alone could leave the double range when R is tiny).  Bm is
-            // positive with alpha >= Q C2R, so its Perron root lies in [max(alpha, 1), 2 max(alpha, 1)]
-            // and the powers of Bm' neither overflow nor underflow.  The row (a, b, r) is carried as
-            // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
-            // r c <- (r c) A'.
-            const double mx = fmax(alpha, 1.0);
-            const int ke = -__builtin_amdgcn_frexp_exp(mx);
-            const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
-            const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;
-            double p00 = al_, p01 = Q_, p10 = C2R_, p11 = c;        // running square Bm'^(2^bit)
-            double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm'^(L-1)
-            bool have = false;
-#pragma unroll
-            for (int bit = 0; (1 << bit) <= L - 1; bit++) {
-                if ((L - 1) & (1 << bit)) {
-                    if (!have) { q00 = p00; q01 = p01; q10 = p10; q11 = p11; have = true; }
-                    else {
-                        const double t00 = fma(q00, p00, q01 * p10), t01 = fma(q00, p01, q01 * p11);
-                        const double t10 = fma(q10, p00, q11 * p10), t11 = fma(q10, p01, q11 * p11);
-                        q00 = t00; q01 = t01; q10 = t10; q11 = t11;
-                    }
-                }
-                if ((2 << bit) <= L - 1) {
-                    const double t00 = fma(p00, p00, p01 * p10), t01 = fma(p00, p01, p01 * p11);
-                    const double t10 = fma(p10, p00, p11 * p10), t11 = fma(p10, p01, p11 * p11);
-                    p00 = t00; p01 = t01; p10 = t10; p11 = t11;
-                }
-            }
-            // Bm'^L = Bm'^(L-1) * Bm'
-            const double r00 = fma(q00, al_, q01 * C2R_), r01 = fma(q00, Q_, q01 * c);
-            const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
-            if (act) {
-                double ra = 0.0, rb = 0.0, rcc = c;
-                auto row = [&](int j) {
-                    const double e = e_at(j), bu = bu_at(j);
-                    gv_[j] = e; Jv[j] = bu;
-                    const double s20 = fma(bu, C2R, ACR * e);
-                    const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
-                    rb = fma(rb, c, fma(ra, Q_, rcc * bu));
-                    ra = na;
-                    rcc *= A_;
-                };
-                if (tail) row(L - 1);
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) row(j);
-                M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
-                M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
-                M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
-                prenorm(M);
-            }
-        } else if (act) {
-            auto f1 = [&](int j) {
-                const bool o = (obsmask >> j) & 1u;
-                const double e = e_at(j), bu = bu_at(j);
-                gv_[j] = e; Jv[j] = bu;
-                const double a00 = o ? alpha : A2;
-                const double g = o ? C2R : 0.0;
-                const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
-                if (j == 0) {
-                    M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
-                } else {
-                    M = pstep(a00, Q, g, s20, bu, A, M);
-                }
-                if ((j & 15) == 15 && j < L - 2) prenorm(M);
-            };
-#pragma unroll
-            for (int j = 0; j < L - 1; j++) f1(j);
-            if (tail) f1(L - 1);
-            prenorm(M);
-        }
-
-        // ------------------------------------------------ forward scan over the cell's LPC lanes
-        M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
-        M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
-        M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
-        prenorm(M);
-        M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
-        if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
-        // exit state of this lane's chunk, then the entry state = exit state of the lane before
-        // (lane 0 of each half: the cell's initial state)
-        const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
-        double n_e = fma(M.m00, n_in, M.m01 * d_in);
-        double d_e = fma(M.m10, n_in, M.m11 * d_in);
-        double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
-        n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
-        d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
-        x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
-        if (vl == 0) { n_e = n_in; d_e = d_in; x_e = x_in; }
-        double Xp, Vp;
-        {
-            const double rd = fast_rcp(d_e);
-            Vp = n_e * rd;
-            Xp = x_e * rd;
-        }
-
-        // ------------------------------------------------ F2: serial re-run from the exact entry
-        double likq = 0.0, sprod = 1.0, Xu = 0.0, Vu = 0.0;
-        int sexp = 0, sneg = 0;
-        double sg = fma(C2, Vp, R);
-        double r0 = fast_rcp(sg);
-        // reverse affine composite of the lane's chunk (B1 of em_scan_impl.h), accumulated in time
-        // order while the steps are produced: (Pi, G, H) o step_j -- no second pass over h_t
-        double Pi = 1.0, G = 0.0, H = 0.0;
-        auto f2 = [&](int j) {
-            const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double e = gv_[j], bu = Jv[j];       // left there by F1
-            const double r = o ? r0 : 0.0;
-            const double sl = o ? sg : 1.0;
-            sprod *= sl;
-            sneg |= __double2hiint(sl);
-            if ((j & 7) == 7) {
-                sexp += __builtin_amdgcn_frexp_exp(sprod);
-                sprod = __builtin_amdgcn_frexp_mant(sprod);
-            }
-            const double w = Vp * r;
-            const double K = C * w;                    // src/EM.cpp:86
-            if (DENSE) Vu = R * w;                     // :88
-            else Vu = fma(-(C2 * w), Vp, Vp);
-            const double dl = fma(-C, Xp, e);
-            Xu = fma(K, dl, Xp);                       // :87
-            likq = fma(dl * r, dl, likq);              // :122
-            const double Vp1 = fma(A2, Vu, Q);         // :76
-            const double Xp1 = fma(A, Xu, bu);         // :74
-            sg = fma(C2, Vp1, R);
-            const double z = fast_rcp(sg * Vp1);
-            const double rp1 = sg * z;
-            r0 = Vp1 * z;
-            const double AVu = A * Vu;
-            double J = AVu * rp1;                      // :100
-            double g = fma(-J, Xp1, Xu);
-            double h = fma(-J, AVu, Vu);
-            if (j >= L - 2) {
-                // step T-1 starts the backward recursion: J = 0, g = Xu, h = Vu, zero terminal value
-                const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
-                J = fin ? 0.0 : J;
-                g = fin ? Xu : g;
-                h = fin ? Vu : h;
-            }
-            Jv[j] = J; gv_[j] = g;
-            if (j < L - 1) hs[j * 64] = h; else hlast = h;
-            G = fma(Pi, g, G);
-            H = fma(Pi * Pi, h, H);
-            Pi *= J;
-            Xp = Xp1;
-            Vp = Vp1;
-            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        };
-        if (act) {
-#pragma unroll
-            for (int j = 0; j < L - 1; j++) f2(j);
-            if (tail) f2(L - 1);
-        }
-        const double termLast = shfl_d(fma(Xu, Xu, Vu), hbase | lastLane);   // Xs^2 + Vs at T-1
-        const double lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
-
-        // ------------------------------------------------ reverse scan of the chunk composites
-#define RSCAN_ROUND(n)                                                     \
-        {                                                                  \
-            const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
-            const double Gb = dppz<DPP_ROW_SHL(n)>(G);                     \
-            const double Hb = dppz<DPP_ROW_SHL(n)>(H);                     \
-            G = fma(Pi, Gb, G);                                            \
-            H = fma(Pi * Pi, Hb, H);                                       \
-            Pi *= Pb;                                                      \
-        }
-        RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
-#undef RSCAN_ROUND
-        if constexpr (LPC == 32) {
-            // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
-            const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
-            const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
-            const int row = lane >> 4;
-            const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
-            const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
-            G = fma(Pi, Gs, G);
-            H = fma(Pi * Pi, Hs, H);
-        }
-        // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
-        // chunk is the next lane's, and the zero terminal value for the half's last lane
-        double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
-        double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
-        if (vl == LPC - 1) { Xn = 0.0; Vn = 0.0; }
-
-        // ------------------------------------------------ B2: serial reverse re-run + M-step sums
-        // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
-        // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
-        // steps, the LDS reads of the series batch freely).
+        // ------------------------------------------------ outputs of the sweeps (either form)
+        double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
+        double addPall = 0.0, addTx1x = 0.0;    // STEADY: closed-form variance sums of the steady region
+        int sneg = 0;
         double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0, aSxx = 0.0;
         double aSxv[QQ], aTx1u[PP], aTux[PP];
 #pragma unroll
         for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
 #pragma unroll
         for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
-        const double XnE = Xn;
-        auto b2a = [&](int j) {
-            const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double J = Jv[j];
-            const double h = (j < L - 1) ? hs[j * 64] : hlast;
-            aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
-            const double Xs = fma(J, Xn, gv_[j]);       // :101
-            const double Vs = fma(J * J, Vn, h);        // :102
-            aPall += Vs;                                // :181,:183
-            if (!DENSE) aSxx += o ? Vs : 0.0;           // :152
-            gv_[j] = Xs;
-            Xn = Xs;
-            Vn = Vs;
-        };
-        auto b2b = [&](int j, bool top) {
-            const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double Xs = gv_[j];
-            const double Xnx = top ? XnE : gv_[top ? j : j + 1];
-            aTx1x = fma(Xnx, Xs, aTx1x);                // :180
+
+        // ------------------------------------------------ STEADY: transient block and verdict
+        // With every y_t observed the variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t:
+        // src/EM.cpp:76,86,88,100) is the data-independent Riccati recursion, which reaches its
+        // fixed point geometrically -- within 15..25 steps for 99 % of the (cell, iteration) pairs
+        // of BASELINE config 2.  The first NTR = L-1 steps of the series (the chunk of lane 0 without
+        // its predicated step) are done ONE STEP PER LANE with the generic machinery (step matrix,
+        // 3x3 scan, the reference's expressions from the exact entry state); lane 31 is no
+        // transient step (NTR <= 31), its "entry state" is the state at t = NTR and what it
+        // evaluates there are the steady constants K, 1/Sigma, Vu, J, h.  Verdict, per CELL (a
+        // cell's arithmetic never depends on its wave partner): one more step leaves Vp unchanged
+        // to 2^-48.  Cells that pass run the steady sweeps below on t >= NTR: only the mean
+        // recursions (affine, constant multipliers), 20 fp64 operations per step where the generic
+        // sweeps take 50, no h_t strip, the variance sums in closed form.  Cells that fail (slow
+        // Riccati convergence: A near 1 with a small gain, mostly in the first EM iterations) take
+        // the generic sweeps for this iteration.
+        constexpr int NTR = L - 1;
+        bool st = false;
+#ifdef LDSR_STEADY_DEBUG
+        double dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        double cK = 0.0, cJ = 0.0, cr = 0.0, cVu = 0.0, ch = 0.0, clg = 0.0, X_tr = 0.0;
+        double trJ = 0.0, trG = 0.0, trH = 0.0, trLq = 0.0, trLg = 0.0;
+        auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl) * 2 + (i & 1)]; };
+        if constexpr (STEADY) {
+            const bool trl = vl < NTR;
+            double e_t = tval(0), bu_t = 0.0;                       // (tri is zero for vl >= NTR)
 #pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) {
-                const double ut = Uat(j, p_);           // zero at t = T-1
-                aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
-                aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
-            }
-            aPall = fma(Xs, Xs, aPall);
-            const double xo = o ? Xs : 0.0;
-            aSyx = fma(Yat(j), xo, aSyx);               // :151
-            if (!DENSE) aSxx = fma(xo, xo, aSxx);
+            for (int q_ = 0; q_ < QQ; q_++) e_t = fma(-th.D[q_], tval(1 + PP + q_), e_t);
 #pragma unroll
-            for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
-            if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-        };
-        if (act) {
-            if (tail) b2a(L - 1);
-            else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
-#pragma unroll
-            for (int j = L - 2; j >= 0; j--) b2a(j);
-            if (tail) b2b(L - 1, true);
-#pragma unroll
-            for (int j = L - 2; j >= 0; j--) b2b(j, false);
+            for (int p_ = 0; p_ < PP; p_++) bu_t = fma(th.B[p_], tval(1 + p_), bu_t);
+            PMat M;
+            M.m00 = trl ? alpha : 1.0; M.m01 = trl ? Q : 0.0;
+            M.m10 = trl ? C2R : 0.0;   M.m11 = 1.0;
+            M.m20 = trl ? fma(bu_t, C2R, ACR * e_t) : 0.0; M.m21 = bu_t; M.m22 = trl ? A : 1.0;
+            prenorm(M);
+            M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
+            M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
+            M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
+            prenorm(M);
+            M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
+            M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));
+            double n_e = fma(M.m00, th.V1, M.m01);
+            double d_e = fma(M.m10, th.V1, M.m11);
+            double x_e = fma(M.m20, th.V1, fma(M.m22, th.mu1, M.m21));
+            n_e = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, n_e);
+            d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
+            x_e = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, x_e);
+            if (vl == 0) { n_e = th.V1; d_e = 1.0; x_e = th.mu1; }
+            const double rd = fast_rcp(d_e);
+            const double Vp = n_e * rd, Xp = x_e * rd;              // state entering step vl (vl >= NTR: t = NTR)
+            const double sg = fma(C2, Vp, R);                       // the reference's expressions, as in F2
+            const double r0 = fast_rcp(sg);
+            const double w = Vp * r0;
+            const double K = C * w;                                 // src/EM.cpp:86
+            const double Vu = R * w;                                // :88
+            const double dl = fma(-C, Xp, e_t);
+            const double Xu = fma(K, dl, Xp);                       // :87
+            const double Vp1 = fma(A2, Vu, Q);                      // :76
+            const double Xp1 = fma(A, Xu, bu_t);                    // :74
+            const double AVu = A * Vu;
+            const double J = AVu * fast_rcp(Vp1);                   // :100
+            trJ = J;
+            trG = fma(-J, Xp1, Xu);
+            trH = fma(-J, AVu, Vu);
+            trLq = trl ? dl * r0 * dl : 0.0;                        // :122
+            const double lg = log_pos(sg);
+            trLg = trl ? lg : 0.0;
+            // fixed point reached, and every Sigma of the block positive (a negative one is the
+            // generic sweeps' business: lik = NaN)
+            const bool conv = fabs(Vp1 - Vp) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0;
+            const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
+            const unsigned long long cvm = __ballot(conv);
+            const unsigned hm = (unsigned)(okm >> hbase), hc = (unsigned)(cvm >> hbase);
+            st = hm == 0xFFFFFFFFu && (hc >> 31) != 0u;
+            const int src = hbase | (LPC - 1);
+            cK = shfl_d(K, src); cJ = shfl_d(J, src); cr = shfl_d(r0, src); cVu = shfl_d(Vu, src);
+            ch = shfl_d(trH, src); clg = shfl_d(lg, src); X_tr = shfl_d(Xp, src);
+#ifdef LDSR_STEADY_DEBUG
+            dbg[0] = Xp; dbg[1] = Vp; dbg[2] = trG; dbg[3] = trJ; dbg[11] = st ? 1.0 : 0.0;
+#endif
         }
-        // Xn, Vn = Xs, Vs at the first step of this lane's chunk
+
+        if (STEADY && st) {
+            // ============================================ steady sweeps over t = NTR .. T-1
+            // Lane 0 keeps only its predicated step L-1 (= step NTR); lanes 1.. their whole chunks.
+            const bool body = act && vl > 0;
+            const double aK = A * cK, a = fma(-aK, C, A);           // Xp_{t+1} = a Xp_t + (A K e_t + B u_t)
+            // a^(L-1), J^(L-1): multipliers of a whole chunk
+            double aL = 1.0, JL = 1.0;
+            {
+                double sa = a, sj = cJ;
+                bool have = false;
+#pragma unroll
+                for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+                    if ((L - 1) & (1 << bit)) {
+                        if (!have) { aL = sa; JL = sj; have = true; }
+                        else { aL *= sa; JL *= sj; }
+                    }
+                    if ((2 << bit) <= L - 1) { sa *= sa; sj *= sj; }
+                }
+            }
+            // ---- F1: chunk composite of the affine mean recursion; e_t, B u_t left for F2
+            double al = 1.0, bl = 0.0;
+            auto f1s = [&](int j) {
+                const double e = e_at(j), bu = bu_at(j);
+                gv_[j] = e; Jv[j] = bu;
+                bl = fma(a, bl, fma(aK, e, bu));
+            };
+            if (body) {
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) f1s(j);
+                al = aL;
+            }
+            if (tail) { f1s(L - 1); al *= a; }
+            // ---- inclusive scan over the cell's lanes, then the entry state of this lane
+#define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
+            SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+#undef SSCAN_ROUND
+            double Xp = fma(al, X_tr, bl);                           // after this lane's steps
+            Xp = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xp);
+            if (vl == 0) Xp = X_tr;
+#ifdef LDSR_STEADY_DEBUG
+            dbg[4] = Xp; dbg[9] = al; dbg[10] = bl;
+#endif
+            // ---- F2: the reference's mean expressions with the steady gains
+            double lq = 0.0, Xu = 0.0;
+            auto f2s = [&](int j) {
+                const double e = gv_[j], bu = Jv[j];
+                const double dl = fma(-C, Xp, e);
+                lq = fma(dl, dl, lq);                              // :122 (times 1/Sigma below)
+                Xu = fma(cK, dl, Xp);                              // :87
+                const double Xp1 = fma(A, Xu, bu);                 // :74
+                double g = fma(-cJ, Xp1, Xu);
+                if (j >= L - 2) {
+                    const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
+                    g = fin ? Xu : g;                              // step T-1: Xs = Xu
+                }
+                gv_[j] = g;
+                Xp = Xp1;
+            };
+            if (body) {
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) f2s(j);
+            }
+            if (tail) f2s(L - 1);
+            tLv = fma(Xu, Xu, cVu);
+            const int nst = (body ? L - 1 : 0) + (tail ? 1 : 0);    // steady steps of this lane
+            likq = fma(cr, lq, trLq);
+            lsp = fma((double)nst, clg, trLg);
+            // ---- reverse composite of the chunk (constant multiplier J), reverse scan
+            double Pi = 1.0, G = 0.0;
+            if (tail) { G = gv_[L - 1]; Pi = cJ; }
+            if (body) {
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) G = fma(cJ, G, gv_[j]);
+                Pi *= JL;
+            }
+#define RSCAN_ROUND(n) { const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi), Gb = dppz<DPP_ROW_SHL(n)>(G); G = fma(Pi, Gb, G); Pi *= Pb; }
+            RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+            {
+                const double G1 = readlane_d(G, 16), G3 = readlane_d(G, 48);
+                const int row = lane >> 4;
+                const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+                G = fma(Pi, Gs, G);
+            }
+            double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+            if (vl == LPC - 1) Xn = 0.0;
+            const double XsS = shfl_d(G, hbase);                    // Xs at t = NTR (lane 0's step L-1)
+#ifdef LDSR_STEADY_DEBUG
+            dbg[5] = Xn; dbg[8] = G;
+#endif
+            // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
+            auto b2s = [&](int j) {
+                const double Xs = fma(cJ, Xn, gv_[j]);             // :101
+                aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    const double ut = Uat(j, p_);                  // zero at t = T-1
+                    aTx1u[p_] = fma(Xn, ut, aTx1u[p_]);            // :190
+                    aTux[p_] = fma(ut, Xs, aTux[p_]);              // :191
+                }
+                aPall = fma(Xs, Xs, aPall);
+                aSyx = fma(Yat(j), Xs, aSyx);                      // :151
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, Vat(j, q_), aSxv[q_]);   // :159
+                Xn = Xs;
+                if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            };
+            if (tail) b2s(L - 1);
+            if (body) {
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) b2s(j);
+            }
+            // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
+            // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
+            const int N = T - NTR;                                   // steps NTR .. T-1
+            const double rho = cJ * cJ;
+            const double romr = fast_rcp(1.0 - rho);
+            const double Vss = ch * romr;
+            const double dV = cVu - Vss;
+            double rN1 = 1.0;                                        // rho^(N-1)
+            {
+                double sq = rho;
+                for (int k = N - 1; k > 0; k >>= 1) {
+                    if (k & 1) rN1 *= sq;
+                    sq *= sq;
+                }
+            }
+            const double VsS = fma(dV, rN1, Vss);                    // Vs at t = NTR
+            const double sumVs = fma(dV * fma(-rN1, rho, 1.0), romr, (double)N * Vss);   // sum_{t >= NTR} Vs_t
+            addPall = sumVs;                                          // :181,:183
+            addTx1x = cJ * (sumVs - VsS);                             // sum_{t=NTR}^{T-2} Vs_{t+1} J_t  (:180)
+            // ---- transient block backwards: composite of steps vl .. NTR-1 applied to (XsS, VsS)
+            {
+                const bool trl = vl < NTR;
+                double Pt = trl ? trJ : 1.0, Gt = trl ? trG : 0.0, Ht = trl ? trH : 0.0;
+#define RSCAN_ROUND(n)                                                     \
+                {                                                          \
+                    const double Pb = dpp1<DPP_ROW_SHL(n)>(Pt);            \
+                    const double Gb = dppz<DPP_ROW_SHL(n)>(Gt);            \
+                    const double Hb = dppz<DPP_ROW_SHL(n)>(Ht);            \
+                    Gt = fma(Pt, Gb, Gt);                                  \
+                    Ht = fma(Pt * Pt, Hb, Ht);                             \
+                    Pt *= Pb;                                              \
+                }
+                RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+                {
+                    const double G1 = readlane_d(Gt, 16), H1 = readlane_d(Ht, 16), P1 = readlane_d(Pt, 16);
+                    const double G3 = readlane_d(Gt, 48), H3 = readlane_d(Ht, 48), P3 = readlane_d(Pt, 48);
+                    const int row = lane >> 4;
+                    const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+                    const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
+                    const double Ps = row == 0 ? P1 : row == 2 ? P3 : 1.0;
+                    Gt = fma(Pt, Gs, Gt);
+                    Ht = fma(Pt * Pt, Hs, Ht);
+                    Pt *= Ps;                    // (the terminal value at t = NTR is not zero here)
+                }
+                const double XsT = fma(Pt, XsS, Gt), VsT = fma(Pt * Pt, VsS, Ht);   // at step vl (vl >= NTR: at NTR)
+                const double XsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, XsT);
+                const double VsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, VsT);
+                if (trl) {
+                    aTx1x = fma(XsN, XsT, fma(VsN, trJ, aTx1x));     // :180
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) {
+                        const double ut = tval(1 + p_);
+                        aTx1u[p_] = fma(XsN, ut, aTx1u[p_]);
+                        aTux[p_] = fma(ut, XsT, aTux[p_]);
+                    }
+                    aPall += fma(XsT, XsT, VsT);
+                    aSyx = fma(tval(0), XsT, aSyx);
+#pragma unroll
+                    for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(XsT, tval(1 + PP + q_), aSxv[q_]);
+                }
+                X0v = XsT; V0v = VsT;                                // lane 0: Xs_0, Vs_0
+#ifdef LDSR_STEADY_DEBUG
+                dbg[6] = XsT; dbg[7] = VsT;
+#endif
+            }
+        } else {
+            // ------------------------------------------------ F1: compose this lane's step matrices;
+            // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
+            PMat M;
+            M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
+            if constexpr (DENSE) {
+                // Every step has the same 2x2 block Bm = [[alpha, Q],[C2R, 1]]: the chunk's block is a
+                // power of it (binary exponentiation) and only the third row needs the per-step
+                // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
+                // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
+                // power of two c = 2^-k with max(alpha, 1) c in [0.5, 1) (projective coordinates are
+                // scale free; alpha^31 alone could leave the double range when R is tiny).  Bm is
+                // positive with alpha >= Q C2R, so its Perron root lies in [max(alpha, 1), 2 max(alpha, 1)]
+                // and the powers of Bm' neither overflow nor underflow.  The row (a, b, r) is carried as
+                // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
+                // r c <- (r c) A'.
+                const double mx = fmax(alpha, 1.0);
+                const int ke = -__builtin_amdgcn_frexp_exp(mx);
+                const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
+                const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;
+                double p00 = al_, p01 = Q_, p10 = C2R_, p11 = c;        // running square Bm'^(2^bit)
+                double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm'^(L-1)
+                bool have = false;
+#pragma unroll
+                for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+                    if ((L - 1) & (1 << bit)) {
+                        if (!have) { q00 = p00; q01 = p01; q10 = p10; q11 = p11; have = true; }
+                        else {
+                            const double t00 = fma(q00, p00, q01 * p10), t01 = fma(q00, p01, q01 * p11);
+                            const double t10 = fma(q10, p00, q11 * p10), t11 = fma(q10, p01, q11 * p11);
+                            q00 = t00; q01 = t01; q10 = t10; q11 = t11;
+                        }
+                    }
+                    if ((2 << bit) <= L - 1) {
+                        const double t00 = fma(p00, p00, p01 * p10), t01 = fma(p00, p01, p01 * p11);
+                        const double t10 = fma(p10, p00, p11 * p10), t11 = fma(p10, p01, p11 * p11);
+                        p00 = t00; p01 = t01; p10 = t10; p11 = t11;
+                    }
+                }
+                // Bm'^L = Bm'^(L-1) * Bm'
+                const double r00 = fma(q00, al_, q01 * C2R_), r01 = fma(q00, Q_, q01 * c);
+                const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
+                if (act) {
+                    double ra = 0.0, rb = 0.0, rcc = c;
+                    auto row = [&](int j) {
+                        const double e = e_at(j), bu = bu_at(j);
+                        gv_[j] = e; Jv[j] = bu;
+                        const double s20 = fma(bu, C2R, ACR * e);
+                        const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
+                        rb = fma(rb, c, fma(ra, Q_, rcc * bu));
+                        ra = na;
+                        rcc *= A_;
+                    };
+                    if (tail) row(L - 1);
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) row(j);
+                    M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
+                    M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
+                    M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
+                    prenorm(M);
+                }
+            } else if (act) {
+                auto f1 = [&](int j) {
+                    const bool o = (obsmask >> j) & 1u;
+                    const double e = e_at(j), bu = bu_at(j);
+                    gv_[j] = e; Jv[j] = bu;
+                    const double a00 = o ? alpha : A2;
+                    const double g = o ? C2R : 0.0;
+                    const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
+                    if (j == 0) {
+                        M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
+                    } else {
+                        M = pstep(a00, Q, g, s20, bu, A, M);
+                    }
+                    if ((j & 15) == 15 && j < L - 2) prenorm(M);
+                };
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) f1(j);
+                if (tail) f1(L - 1);
+                prenorm(M);
+            }
+
+            // ------------------------------------------------ forward scan over the cell's LPC lanes
+            M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
+            M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
+            M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
+            prenorm(M);
+            M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
+            if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+            // exit state of this lane's chunk, then the entry state = exit state of the lane before
+            // (lane 0 of each half: the cell's initial state)
+            const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
+            double n_e = fma(M.m00, n_in, M.m01 * d_in);
+            double d_e = fma(M.m10, n_in, M.m11 * d_in);
+            double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
+            n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
+            d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
+            x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
+            if (vl == 0) { n_e = n_in; d_e = d_in; x_e = x_in; }
+            double Xp, Vp;
+            {
+                const double rd = fast_rcp(d_e);
+                Vp = n_e * rd;
+                Xp = x_e * rd;
+            }
+
+            // ------------------------------------------------ F2: serial re-run from the exact entry
+            double sprod = 1.0, Xu = 0.0, Vu = 0.0;
+            int sexp = 0;
+            double sg = fma(C2, Vp, R);
+            double r0 = fast_rcp(sg);
+            // reverse affine composite of the lane's chunk (B1 of em_scan_impl.h), accumulated in time
+            // order while the steps are produced: (Pi, G, H) o step_j -- no second pass over h_t
+            double Pi = 1.0, G = 0.0, H = 0.0;
+            auto f2 = [&](int j) {
+                const bool o = DENSE || ((obsmask >> j) & 1u);
+                const double e = gv_[j], bu = Jv[j];       // left there by F1
+                const double r = o ? r0 : 0.0;
+                const double sl = o ? sg : 1.0;
+                sprod *= sl;
+                sneg |= __double2hiint(sl);
+                if ((j & 7) == 7) {
+                    sexp += __builtin_amdgcn_frexp_exp(sprod);
+                    sprod = __builtin_amdgcn_frexp_mant(sprod);
+                }
+                const double w = Vp * r;
+                const double K = C * w;                    // src/EM.cpp:86
+                if (DENSE) Vu = R * w;                     // :88
+                else Vu = fma(-(C2 * w), Vp, Vp);
+                const double dl = fma(-C, Xp, e);
+                Xu = fma(K, dl, Xp);                       // :87
+                likq = fma(dl * r, dl, likq);              // :122
+                const double Vp1 = fma(A2, Vu, Q);         // :76
+                const double Xp1 = fma(A, Xu, bu);         // :74
+                sg = fma(C2, Vp1, R);
+                const double z = fast_rcp(sg * Vp1);
+                const double rp1 = sg * z;
+                r0 = Vp1 * z;
+                const double AVu = A * Vu;
+                double J = AVu * rp1;                      // :100
+                double g = fma(-J, Xp1, Xu);
+                double h = fma(-J, AVu, Vu);
+                if (j >= L - 2) {
+                    // step T-1 starts the backward recursion: J = 0, g = Xu, h = Vu, zero terminal value
+                    const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
+                    J = fin ? 0.0 : J;
+                    g = fin ? Xu : g;
+                    h = fin ? Vu : h;
+                }
+                Jv[j] = J; gv_[j] = g;
+                if (j < L - 1) hs[j * 64] = h; else hlast = h;
+                G = fma(Pi, g, G);
+                H = fma(Pi * Pi, h, H);
+                Pi *= J;
+                Xp = Xp1;
+                Vp = Vp1;
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            };
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) f2(j);
+                if (tail) f2(L - 1);
+            }
+            tLv = fma(Xu, Xu, Vu);                                                // Xs^2 + Vs at T-1 (in lastLane)
+            lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
+
+            // ------------------------------------------------ reverse scan of the chunk composites
+#define RSCAN_ROUND(n)                                                     \
+            {                                                                  \
+                const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
+                const double Gb = dppz<DPP_ROW_SHL(n)>(G);                     \
+                const double Hb = dppz<DPP_ROW_SHL(n)>(H);                     \
+                G = fma(Pi, Gb, G);                                            \
+                H = fma(Pi * Pi, Hb, H);                                       \
+                Pi *= Pb;                                                      \
+            }
+            RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+            if constexpr (LPC == 32) {
+                // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
+                const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
+                const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
+                const int row = lane >> 4;
+                const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+                const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
+                G = fma(Pi, Gs, G);
+                H = fma(Pi * Pi, Hs, H);
+            }
+            // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
+            // chunk is the next lane's, and the zero terminal value for the half's last lane
+            double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+            double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
+            if (vl == LPC - 1) { Xn = 0.0; Vn = 0.0; }
+
+            // ------------------------------------------------ B2: serial reverse re-run + M-step sums
+            // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
+            // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
+            // steps, the LDS reads of the series batch freely).
+            const double XnE = Xn;
+            auto b2a = [&](int j) {
+                const bool o = DENSE || ((obsmask >> j) & 1u);
+                const double J = Jv[j];
+                const double h = (j < L - 1) ? hs[j * 64] : hlast;
+                aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
+                const double Xs = fma(J, Xn, gv_[j]);       // :101
+                const double Vs = fma(J * J, Vn, h);        // :102
+                aPall += Vs;                                // :181,:183
+                if (!DENSE) aSxx += o ? Vs : 0.0;           // :152
+                gv_[j] = Xs;
+                Xn = Xs;
+                Vn = Vs;
+            };
+            auto b2b = [&](int j, bool top) {
+                const bool o = DENSE || ((obsmask >> j) & 1u);
+                const double Xs = gv_[j];
+                const double Xnx = top ? XnE : gv_[top ? j : j + 1];
+                aTx1x = fma(Xnx, Xs, aTx1x);                // :180
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    const double ut = Uat(j, p_);           // zero at t = T-1
+                    aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
+                    aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
+                }
+                aPall = fma(Xs, Xs, aPall);
+                const double xo = o ? Xs : 0.0;
+                aSyx = fma(Yat(j), xo, aSyx);               // :151
+                if (!DENSE) aSxx = fma(xo, xo, aSxx);
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
+                if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            };
+            if (act) {
+                if (tail) b2a(L - 1);
+                else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) b2a(j);
+                if (tail) b2b(L - 1, true);
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) b2b(j, false);
+            }
+            // Xn, Vn = Xs, Vs at the first step of this lane's chunk
+            X0v = Xn; V0v = Vn;
+
+        }
 
         // ------------------------------------------------ one reduction per half, M-step, stop rule
         Sums<PP, QQ> S;
@@ -491,8 +783,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 for (int i = 0; i < NR; i++)
                     red[i] = shfl_d(red_slot(i, NR, LPC) == 0 ? t0 : t1, hbase | red_home(i, NR, LPC));
             }
-            S.X0 = shfl_d(Xn, hbase);                // :218
-            S.V0 = shfl_d(Vn, hbase);                // :219
+            S.X0 = shfl_d(X0v, hbase);               // :218
+            S.V0 = shfl_d(V0v, hbase);               // :219
+            const double termLast = shfl_d(tLv, hbase | lastLane);
+            if constexpr (STEADY) { red[1] += addTx1x; red[2] += addPall; }
             if constexpr (LEAD) {
                 // (delta, eps) at the tail's first step close the lead's sums; mu1 / V1 come from t = 0
                 const double dlt = S.X0 - x_t1, eps = S.V0 - v_t1;
@@ -542,6 +836,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 prm.lik[cell] = lik;
                 prm.status[cell] = (abort_now && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
             }
+#ifdef LDSR_STEADY_DEBUG
+            if (prm.liks && cell == c0 && 16 + 12 * LPC <= prm.niter)
+                for (int i = 0; i < 12; i++) prm.liks[(long)cell * prm.niter + 16 + i * LPC + vl] = dbg[i];
+#endif
             alive = false;
             if constexpr (QUEUE) {
                 if (!abort_now) {
@@ -585,6 +883,16 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
         const double *g3 = prm.img3 + (long)s * prm.img3_stride;
         for (int i = threadIdx.x; i < n3; i += blockDim.x) lu[i] = g3[i];
     }
+    // STEADY: the first L-1 steps (lane 0's chunk) once more, one step per lane, zero beyond
+    constexpr bool STEADY = !LEAD && pair_steady(L, LPC, PP, QQ);
+    const double *tri = lu;
+    if constexpr (STEADY) {
+        constexpr int KP = scan_pairs(PP, QQ);
+        for (int i = threadIdx.x; i < KP * LPC * 2; i += blockDim.x) {
+            const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;
+            lu[i] = l < L - 1 ? gimg[((l * KP + m) * LPC) * 2 + c] : 0.0;
+        }
+    }
     __syncthreads();
     const SeriesConst *sc = prm.sc + s;
     if (sc->status != 0) {
@@ -606,10 +914,10 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     double *hs = smem + IMG + (long)wave * pair_strip_doubles(L) + lane;
     const bool dense = sc->n_obs == prm.T;
     if constexpr (LEAD) {
-        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
     } else {
-        if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
-        else em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+        if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE, false, STEADY>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
+        else em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
     }
 }
 

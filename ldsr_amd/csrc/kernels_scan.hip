@@ -133,7 +133,8 @@ int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
     if (wpb_env == 8) return 8;
     const int w = wpb_env == 2 ? 2 : 4;
     const size_t lds = ((size_t)pair_image_doubles(p.L, PP, QQ, lpc) + (size_t)w * pair_strip_doubles(p.L) +
-                        (lead > 0 ? (size_t)pair_lead_doubles(lead, lpc, PP) : 0)) * sizeof(double);
+                        (lead > 0 ? (size_t)pair_lead_doubles(lead, lpc, PP) : 0) +
+                        (lead == 0 && pair_steady(p.L, lpc, PP, QQ) ? (size_t)pair_tri_doubles(PP, QQ, lpc) : 0)) * sizeof(double);
     // (the runtime keeps some LDS per workgroup for itself: leave 1 KiB per workgroup free)
     return (8 / w) * (lds + 1024) <= kLdsBytes ? w : 8;
 }
