@@ -47,6 +47,15 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY            // 0: every dense cell takes the generic sweeps (A/B builds)
 #define LDSR_STEADY 1
 #endif
+#ifndef LDSR_STEADY_PF         // steady sweeps: prefetch distance of the LDS image reads, in steps
+#define LDSR_STEADY_PF 4
+#endif
+#ifndef LDSR_STEADY_PF2        // ... and of the strip reads in F2
+#define LDSR_STEADY_PF2 6
+#endif
+#ifndef LDSR_STEADY_SBMASK     // what may still cross the per-step scheduling barriers (0x2 VALU | 0x4 SALU)
+#define LDSR_STEADY_SBMASK 0x6
+#endif
 #ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
 #define LDSR_STEADY_MIN_L 24
 #endif
@@ -56,6 +65,320 @@ __host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
 }
 
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
+
+// Sums and likelihood terms of one E-step, as the sweeps leave them in every lane (reduced over the
+// cell's lanes afterwards by em_pair_body)
+template <int PP, int QQ>
+struct PairSweepOut {
+    double aSyx, aTx1x, aPall, aSxx, likq, lsp, tLv, X0v, V0v;
+    double aSxv[QQ], aTx1u[PP], aTux[PP];
+    int sneg;
+};
+
+// The generic sweeps of one E-step for the cell of this lane (any observation mask): F1 / forward
+// scan / F2, reverse scan, B2 -- em_scan_impl.h's algorithm on LPC-lane cells, see the head of this
+// file.  (x_in, v_in) is the state at the first step of the sweeps (mu1, V1; LEAD: the state at the
+// tail's first step).  hs: this lane's column of the wave's h_t strip.
+template <int PP, int QQ, int L, int LPC, bool DENSE>
+__device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> &th,
+                                                    const double *ys, double *hs, unsigned obsmask,
+                                                    int lane, int nl, int rp, double x_t1, double v_t1) {
+    constexpr int KP = scan_pairs(PP, QQ);
+    const int vl = lane & (LPC - 1);
+    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
+    auto Yat = [&](int j) { return val(j, 0); };
+    auto Uat = [&](int j, int k) { return val(j, 1 + k); };
+    auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
+    const bool act = vl < nl, tail = vl < rp;
+    const int lastLane = nl - 1;
+    const double A = th.A, C = th.C, Q = th.Q, R = th.R;
+    const double A2 = A * A, C2 = C * C;
+    const double rR = fast_rcp(R);
+    const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
+    auto e_at = [&](int j) {
+        double e = Yat(j);
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], Vat(j, q_), e);
+        return e;
+    };
+    auto bu_at = [&](int j) {
+        double bu = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
+        return bu;
+    };
+    double Jv[L], gv_[L];
+    double hlast = 0.0;      // h of the predicated step L-1
+    double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
+    int sneg = 0;
+    double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0, aSxx = 0.0;
+    double aSxv[QQ], aTx1u[PP], aTux[PP];
+#pragma unroll
+    for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+#pragma unroll
+    for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+
+    // ------------------------------------------------ F1: compose this lane's step matrices;
+    // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
+    PMat M;
+    M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
+    if constexpr (DENSE) {
+        // Every step has the same 2x2 block Bm = [[alpha, Q],[C2R, 1]]: the chunk's block is a
+        // power of it (binary exponentiation) and only the third row needs the per-step
+        // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
+        // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
+        // power of two c = 2^-k with max(alpha, 1) c in [0.5, 1) (projective coordinates are
+        // scale free; alpha^31 alone could leave the double range when R is tiny).  Bm is
+        // positive with alpha >= Q C2R, so its Perron root lies in [max(alpha, 1), 2 max(alpha, 1)]
+        // and the powers of Bm' neither overflow nor underflow.  The row (a, b, r) is carried as
+        // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
+        // r c <- (r c) A'.
+        const double mx = fmax(alpha, 1.0);
+        const int ke = -__builtin_amdgcn_frexp_exp(mx);
+        const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
+        const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;
+        double p00 = al_, p01 = Q_, p10 = C2R_, p11 = c;        // running square Bm'^(2^bit)
+        double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm'^(L-1)
+        bool have = false;
+#pragma unroll
+        for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+            if ((L - 1) & (1 << bit)) {
+                if (!have) { q00 = p00; q01 = p01; q10 = p10; q11 = p11; have = true; }
+                else {
+                    const double t00 = fma(q00, p00, q01 * p10), t01 = fma(q00, p01, q01 * p11);
+                    const double t10 = fma(q10, p00, q11 * p10), t11 = fma(q10, p01, q11 * p11);
+                    q00 = t00; q01 = t01; q10 = t10; q11 = t11;
+                }
+            }
+            if ((2 << bit) <= L - 1) {
+                const double t00 = fma(p00, p00, p01 * p10), t01 = fma(p00, p01, p01 * p11);
+                const double t10 = fma(p10, p00, p11 * p10), t11 = fma(p10, p01, p11 * p11);
+                p00 = t00; p01 = t01; p10 = t10; p11 = t11;
+            }
+        }
+        // Bm'^L = Bm'^(L-1) * Bm'
+        const double r00 = fma(q00, al_, q01 * C2R_), r01 = fma(q00, Q_, q01 * c);
+        const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
+        if (act) {
+            double ra = 0.0, rb = 0.0, rcc = c;
+            auto row = [&](int j) {
+                const double e = e_at(j), bu = bu_at(j);
+                gv_[j] = e; Jv[j] = bu;
+                const double s20 = fma(bu, C2R, ACR * e);
+                const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
+                rb = fma(rb, c, fma(ra, Q_, rcc * bu));
+                ra = na;
+                rcc *= A_;
+            };
+            if (tail) row(L - 1);
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) row(j);
+            M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
+            M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
+            M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
+            prenorm(M);
+        }
+    } else if (act) {
+        auto f1 = [&](int j) {
+            const bool o = (obsmask >> j) & 1u;
+            const double e = e_at(j), bu = bu_at(j);
+            gv_[j] = e; Jv[j] = bu;
+            const double a00 = o ? alpha : A2;
+            const double g = o ? C2R : 0.0;
+            const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
+            if (j == 0) {
+                M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
+            } else {
+                M = pstep(a00, Q, g, s20, bu, A, M);
+            }
+            if ((j & 15) == 15 && j < L - 2) prenorm(M);
+        };
+#pragma unroll
+        for (int j = 0; j < L - 1; j++) f1(j);
+        if (tail) f1(L - 1);
+        prenorm(M);
+    }
+
+    // ------------------------------------------------ forward scan over the cell's LPC lanes
+    M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
+    M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
+    M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
+    prenorm(M);
+    M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
+    if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+    // exit state of this lane's chunk, then the entry state = exit state of the lane before
+    // (lane 0 of each half: the cell's initial state)
+    const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
+    double n_e = fma(M.m00, n_in, M.m01 * d_in);
+    double d_e = fma(M.m10, n_in, M.m11 * d_in);
+    double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
+    n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
+    d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
+    x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
+    if (vl == 0) { n_e = n_in; d_e = d_in; x_e = x_in; }
+    double Xp, Vp;
+    {
+        const double rd = fast_rcp(d_e);
+        Vp = n_e * rd;
+        Xp = x_e * rd;
+    }
+
+    // ------------------------------------------------ F2: serial re-run from the exact entry
+    double sprod = 1.0, Xu = 0.0, Vu = 0.0;
+    int sexp = 0;
+    double sg = fma(C2, Vp, R);
+    double r0 = fast_rcp(sg);
+    // reverse affine composite of the lane's chunk (B1 of em_scan_impl.h), accumulated in time
+    // order while the steps are produced: (Pi, G, H) o step_j -- no second pass over h_t
+    double Pi = 1.0, G = 0.0, H = 0.0;
+    auto f2 = [&](int j) {
+        const bool o = DENSE || ((obsmask >> j) & 1u);
+        const double e = gv_[j], bu = Jv[j];       // left there by F1
+        const double r = o ? r0 : 0.0;
+        const double sl = o ? sg : 1.0;
+        sprod *= sl;
+        sneg |= __double2hiint(sl);
+        if ((j & 7) == 7) {
+            sexp += __builtin_amdgcn_frexp_exp(sprod);
+            sprod = __builtin_amdgcn_frexp_mant(sprod);
+        }
+        const double w = Vp * r;
+        const double K = C * w;                    // src/EM.cpp:86
+        if (DENSE) Vu = R * w;                     // :88
+        else Vu = fma(-(C2 * w), Vp, Vp);
+        const double dl = fma(-C, Xp, e);
+        Xu = fma(K, dl, Xp);                       // :87
+        likq = fma(dl * r, dl, likq);              // :122
+        const double Vp1 = fma(A2, Vu, Q);         // :76
+        const double Xp1 = fma(A, Xu, bu);         // :74
+        sg = fma(C2, Vp1, R);
+        const double z = fast_rcp(sg * Vp1);
+        const double rp1 = sg * z;
+        r0 = Vp1 * z;
+        const double AVu = A * Vu;
+        double J = AVu * rp1;                      // :100
+        double g = fma(-J, Xp1, Xu);
+        double h = fma(-J, AVu, Vu);
+        if (j >= L - 2) {
+            // step T-1 starts the backward recursion: J = 0, g = Xu, h = Vu, zero terminal value
+            const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
+            J = fin ? 0.0 : J;
+            g = fin ? Xu : g;
+            h = fin ? Vu : h;
+        }
+        Jv[j] = J; gv_[j] = g;
+        if (j < L - 1) hs[j * 64] = h; else hlast = h;
+        G = fma(Pi, g, G);
+        H = fma(Pi * Pi, h, H);
+        Pi *= J;
+        Xp = Xp1;
+        Vp = Vp1;
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    };
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < L - 1; j++) f2(j);
+        if (tail) f2(L - 1);
+    }
+    tLv = fma(Xu, Xu, Vu);                                                // Xs^2 + Vs at T-1 (in lastLane)
+    lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
+
+    // ------------------------------------------------ reverse scan of the chunk composites
+#define RSCAN_ROUND(n)                                                     \
+    {                                                                  \
+        const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
+        const double Gb = dppz<DPP_ROW_SHL(n)>(G);                     \
+        const double Hb = dppz<DPP_ROW_SHL(n)>(H);                     \
+        G = fma(Pi, Gb, G);                                            \
+        H = fma(Pi * Pi, Hb, H);                                       \
+        Pi *= Pb;                                                      \
+    }
+    RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+    if constexpr (LPC == 32) {
+        // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
+        const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
+        const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
+        const int row = lane >> 4;
+        const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+        const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
+        G = fma(Pi, Gs, G);
+        H = fma(Pi * Pi, Hs, H);
+    }
+    // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
+    // chunk is the next lane's, and the zero terminal value for the half's last lane
+    double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+    double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
+    if (vl == LPC - 1) { Xn = 0.0; Vn = 0.0; }
+
+    // ------------------------------------------------ B2: serial reverse re-run + M-step sums
+    // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
+    // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
+    // steps, the LDS reads of the series batch freely).
+    const double XnE = Xn;
+    auto b2a = [&](int j) {
+        const bool o = DENSE || ((obsmask >> j) & 1u);
+        const double J = Jv[j];
+        const double h = (j < L - 1) ? hs[j * 64] : hlast;
+        aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
+        const double Xs = fma(J, Xn, gv_[j]);       // :101
+        const double Vs = fma(J * J, Vn, h);        // :102
+        aPall += Vs;                                // :181,:183
+        if (!DENSE) aSxx += o ? Vs : 0.0;           // :152
+        gv_[j] = Xs;
+        Xn = Xs;
+        Vn = Vs;
+    };
+    auto b2b = [&](int j, bool top) {
+        const bool o = DENSE || ((obsmask >> j) & 1u);
+        const double Xs = gv_[j];
+        const double Xnx = top ? XnE : gv_[top ? j : j + 1];
+        aTx1x = fma(Xnx, Xs, aTx1x);                // :180
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) {
+            const double ut = Uat(j, p_);           // zero at t = T-1
+            aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
+            aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
+        }
+        aPall = fma(Xs, Xs, aPall);
+        const double xo = o ? Xs : 0.0;
+        aSyx = fma(Yat(j), xo, aSyx);               // :151
+        if (!DENSE) aSxx = fma(xo, xo, aSxx);
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
+        if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    };
+    if (act) {
+        if (tail) b2a(L - 1);
+        else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
+#pragma unroll
+        for (int j = L - 2; j >= 0; j--) b2a(j);
+        if (tail) b2b(L - 1, true);
+#pragma unroll
+        for (int j = L - 2; j >= 0; j--) b2b(j, false);
+    }
+    // Xn, Vn = Xs, Vs at the first step of this lane's chunk
+    X0v = Xn; V0v = Vn;
+
+    o.aSyx = aSyx; o.aTx1x = aTx1x; o.aPall = aPall; o.aSxx = aSxx;
+    o.likq = likq; o.lsp = lsp; o.tLv = tLv; o.X0v = X0v; o.V0v = V0v; o.sneg = sneg;
+#pragma unroll
+    for (int q_ = 0; q_ < QQ; q_++) o.aSxv[q_] = aSxv[q_];
+#pragma unroll
+    for (int p_ = 0; p_ < PP; p_++) { o.aTx1u[p_] = aTx1u[p_]; o.aTux[p_] = aTux[p_]; }
+}
+// The same as a real call: in the STEADY form of em_pair_body the generic sweeps are the rare
+// fallback (cells whose Riccati recursion has not converged within the transient block), and
+// inlined next to the steady sweeps their 244 registers made the allocator spill values that live
+// across the whole EM loop on the steady path too.
+template <int PP, int QQ, int L, int LPC, bool DENSE>
+__device__ __attribute__((noinline)) void pair_generic_sweeps_call(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> &th,
+                                                                   const double *ys, double *hs, unsigned obsmask,
+                                                                   int lane, int nl, int rp, double x_t1, double v_t1) {
+    PairSweepOut<PP, QQ> t;
+    pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(t, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+    o = t;
+}
 
 template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD, bool STEADY = false>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
@@ -69,9 +392,13 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     // `half` = which cell of the wave this lane works for (the name dates from LPC = 32)
     const int half = lane / LPC, vl = lane & (LPC - 1), hbase = lane & ~(LPC - 1);
     auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
-    auto Yat = [&](int j) { return val(j, 0); };
-    auto Uat = [&](int j, int k) { return val(j, 1 + k); };
-    auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
+    // all 2 KP values of step j of this lane (ds_read_b128 each pair)
+    auto ldw = [&](int j, double (&w)[2 * KP]) {
+#pragma unroll
+        for (int i = 0; i < 2 * KP; i++) w[i] = val(j, i);
+    };
+    constexpr int PF = LDSR_STEADY_PF;       // steady sweeps: steps the image is read ahead
+    constexpr int PF2 = LDSR_STEADY_PF2;     // ... and the strip
     // LEAD: the first `lead` steps of every series of the launch are unobserved and are handled in
     // closed form (below); the sweeps work on the tail [lead, T) only, all indices tail relative
     const int lead = LEAD ? prm.lead : 0;
@@ -110,8 +437,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
-    double Jv[L], gv_[L];
-    double hlast = 0.0;      // h of the predicated step L-1
+    double gv_[STEADY ? L : 1];   // steady sweeps: e_t, then g_t of this lane's steps
     int wit = 0;             // wave-uniform iteration count (interrupt poll)
 
     while (__any(alive)) {
@@ -119,19 +445,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         const double A2 = A * A, C2 = C * C;
         const double rR = fast_rcp(R);
         const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
-
-        auto e_at = [&](int j) {
-            double e = Yat(j);
-#pragma unroll
-            for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], Vat(j, q_), e);
-            return e;
-        };
-        auto bu_at = [&](int j) {
-            double bu = 0.0;
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
-            return bu;
-        };
 
         // ------------------------------------------------ LEAD: the all-missing first `lead` steps
         // Over unobserved steps K_t = 0 (src/EM.cpp:82-84): Xp_{t+1} = A Xp_t + B u_t and
@@ -318,7 +631,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
             const unsigned long long cvm = __ballot(conv);
             const unsigned hm = (unsigned)(okm >> hbase), hc = (unsigned)(cvm >> hbase);
-            st = hm == 0xFFFFFFFFu && (hc >> 31) != 0u;
+            st = alive && hm == 0xFFFFFFFFu && (hc >> 31) != 0u;
             const int src = hbase | (LPC - 1);
             cK = shfl_d(K, src); cJ = shfl_d(J, src); cr = shfl_d(r0, src); cVu = shfl_d(Vu, src);
             ch = shfl_d(trH, src); clg = shfl_d(lg, src); X_tr = shfl_d(Xp, src);
@@ -327,7 +640,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
         }
 
-        if (STEADY && st) {
+        if (STEADY && __builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
             // ============================================ steady sweeps over t = NTR .. T-1
             // Lane 0 keeps only its predicated step L-1 (= step NTR); lanes 1.. their whole chunks.
             const bool body = act && vl > 0;
@@ -346,19 +659,40 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     if ((2 << bit) <= L - 1) { sa *= sa; sj *= sj; }
                 }
             }
-            // ---- F1: chunk composite of the affine mean recursion; e_t, B u_t left for F2
-            double al = 1.0, bl = 0.0;
-            auto f1s = [&](int j) {
-                const double e = e_at(j), bu = bu_at(j);
-                gv_[j] = e; Jv[j] = bu;
+            // ---- F1: chunk composite of the affine mean recursion; e_t, B u_t left for F2.
+            // The series image is read PF steps ahead through an explicit register ring pinned by
+            // scheduling barriers: left alone, the scheduler issued each ds_read_b128 right before
+            // its use (one read in flight, 35 ns exposed per read: the sweeps were LDS-latency bound).
+            // (the strip is free here: the steady sweeps have no h_t; J_t's registers stay unused, which
+            // is what makes room for the read-ahead rings at two waves per SIMD)
+            double al = 1.0, bl = 0.0, buLast = 0.0;
+            auto f1s = [&](int j, const double (&w)[2 * KP]) {
+                double e = w[0], bu = 0.0;
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], w[1 + PP + q_], e);
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], w[1 + p_], bu);
+                gv_[j] = e;
+                if (j < L - 1) hs[j * 64] = bu; else buLast = bu;     // B u_t waits for F2 in the wave's LDS strip
                 bl = fma(a, bl, fma(aK, e, bu));
             };
-            if (body) {
+            {
+                double Wt[2 * KP], W[PF][2 * KP];
+                ldw(L - 1, Wt);
 #pragma unroll
-                for (int j = 0; j < L - 1; j++) f1s(j);
-                al = aL;
+                for (int d = 0; d < PF; d++) ldw(d, W[d]);
+                __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                if (body) {
+#pragma unroll
+                    for (int j = 0; j < L - 1; j++) {
+                        f1s(j, W[j % PF]);
+                        if (j + PF < L - 1) ldw(j + PF, W[j % PF]);
+                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    }
+                    al = aL;
+                }
+                if (tail) { f1s(L - 1, Wt); al *= a; }
             }
-            if (tail) { f1s(L - 1); al *= a; }
             // ---- inclusive scan over the cell's lanes, then the entry state of this lane
 #define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
             SSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
@@ -375,8 +709,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
             // ---- F2: the reference's mean expressions with the steady gains
             double lq = 0.0, Xu = 0.0;
-            auto f2s = [&](int j) {
-                const double e = gv_[j], bu = Jv[j];
+            auto f2s = [&](int j, double bu) {
+                const double e = gv_[j];
                 const double dl = fma(-C, Xp, e);
                 lq = fma(dl, dl, lq);                              // :122 (times 1/Sigma below)
                 Xu = fma(cK, dl, Xp);                              // :87
@@ -390,10 +724,24 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 Xp = Xp1;
             };
             if (body) {
+                double U[PF2];
 #pragma unroll
-                for (int j = 0; j < L - 1; j++) f2s(j);
+                for (int d = 0; d < PF2; d++) U[d] = hs[d * 64];
+                __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) {
+                    f2s(j, U[j % PF2]);
+                    if (j + PF2 < L - 1) U[j % PF2] = hs[(j + PF2) * 64];
+                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                }
             }
-            if (tail) f2s(L - 1);
+            if (tail) f2s(L - 1, buLast);
+            // B2's first reads of the image are issued here, ahead of the reverse scan
+            double Vt[2 * KP], V[PF][2 * KP];
+            ldw(L - 1, Vt);
+#pragma unroll
+            for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+            __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
             tLv = fma(Xu, Xu, cVu);
             const int nst = (body ? L - 1 : 0) + (tail ? 1 : 0);    // steady steps of this lane
             likq = fma(cr, lq, trLq);
@@ -422,26 +770,30 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             dbg[5] = Xn; dbg[8] = G;
 #endif
             // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
-            auto b2s = [&](int j) {
+            auto b2s = [&](int j, const double (&w)[2 * KP]) {
                 const double Xs = fma(cJ, Xn, gv_[j]);             // :101
                 aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
 #pragma unroll
                 for (int p_ = 0; p_ < PP; p_++) {
-                    const double ut = Uat(j, p_);                  // zero at t = T-1
+                    const double ut = w[1 + p_];                   // zero at t = T-1
                     aTx1u[p_] = fma(Xn, ut, aTx1u[p_]);            // :190
                     aTux[p_] = fma(ut, Xs, aTux[p_]);              // :191
                 }
                 aPall = fma(Xs, Xs, aPall);
-                aSyx = fma(Yat(j), Xs, aSyx);                      // :151
+                aSyx = fma(w[0], Xs, aSyx);                        // :151
 #pragma unroll
-                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, Vat(j, q_), aSxv[q_]);   // :159
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, w[1 + PP + q_], aSxv[q_]);   // :159
                 Xn = Xs;
-                if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
             };
-            if (tail) b2s(L - 1);
+            if (tail) b2s(L - 1, Vt);
             if (body) {
 #pragma unroll
-                for (int j = L - 2; j >= 0; j--) b2s(j);
+                for (int j = L - 2; j >= 0; j--) {
+                    const int d = (L - 2 - j) % PF;
+                    b2s(j, V[d]);
+                    if (j - PF >= 0) ldw(j - PF, V[d]);
+                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                }
             }
             // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
             // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
@@ -509,249 +861,18 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 dbg[6] = XsT; dbg[7] = VsT;
 #endif
             }
-        } else {
-            // ------------------------------------------------ F1: compose this lane's step matrices;
-            // e_t and B u_t are handed to F2 through the (not yet live) g_t / J_t slots
-            PMat M;
-            M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
-            if constexpr (DENSE) {
-                // Every step has the same 2x2 block Bm = [[alpha, Q],[C2R, 1]]: the chunk's block is a
-                // power of it (binary exponentiation) and only the third row needs the per-step
-                // recursion, composed from the chunk's last step towards its first (em_scan_impl.h).
-                // Chunks are up to 32 steps long here, so the step matrix is first scaled by an exact
-                // power of two c = 2^-k with max(alpha, 1) c in [0.5, 1) (projective coordinates are
-                // scale free; alpha^31 alone could leave the double range when R is tiny).  Bm is
-                // positive with alpha >= Q C2R, so its Perron root lies in [max(alpha, 1), 2 max(alpha, 1)]
-                // and the powers of Bm' neither overflow nor underflow.  The row (a, b, r) is carried as
-                // (a, b, r c):   a <- a alpha' + b C2R' + (r c) s20_j,   b <- b c + a Q' + (r c) bu_j,
-                // r c <- (r c) A'.
-                const double mx = fmax(alpha, 1.0);
-                const int ke = -__builtin_amdgcn_frexp_exp(mx);
-                const double c = __builtin_amdgcn_ldexp(1.0, ke), cinv = __builtin_amdgcn_ldexp(1.0, -ke);
-                const double al_ = alpha * c, Q_ = Q * c, C2R_ = C2R * c, A_ = A * c;
-                double p00 = al_, p01 = Q_, p10 = C2R_, p11 = c;        // running square Bm'^(2^bit)
-                double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm'^(L-1)
-                bool have = false;
+        } else if (!STEADY || alive) {
+#ifndef LDSR_STEADY_ONLY_EXPERIMENT   // (timing experiment: no fallback at all -- results wrong for slow cells)
+            PairSweepOut<PP, QQ> o;
+            if constexpr (STEADY) pair_generic_sweeps_call<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+            else pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+            aSyx = o.aSyx; aTx1x = o.aTx1x; aPall = o.aPall; aSxx = o.aSxx;
+            likq = o.likq; lsp = o.lsp; tLv = o.tLv; X0v = o.X0v; V0v = o.V0v; sneg = o.sneg;
 #pragma unroll
-                for (int bit = 0; (1 << bit) <= L - 1; bit++) {
-                    if ((L - 1) & (1 << bit)) {
-                        if (!have) { q00 = p00; q01 = p01; q10 = p10; q11 = p11; have = true; }
-                        else {
-                            const double t00 = fma(q00, p00, q01 * p10), t01 = fma(q00, p01, q01 * p11);
-                            const double t10 = fma(q10, p00, q11 * p10), t11 = fma(q10, p01, q11 * p11);
-                            q00 = t00; q01 = t01; q10 = t10; q11 = t11;
-                        }
-                    }
-                    if ((2 << bit) <= L - 1) {
-                        const double t00 = fma(p00, p00, p01 * p10), t01 = fma(p00, p01, p01 * p11);
-                        const double t10 = fma(p10, p00, p11 * p10), t11 = fma(p10, p01, p11 * p11);
-                        p00 = t00; p01 = t01; p10 = t10; p11 = t11;
-                    }
-                }
-                // Bm'^L = Bm'^(L-1) * Bm'
-                const double r00 = fma(q00, al_, q01 * C2R_), r01 = fma(q00, Q_, q01 * c);
-                const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
-                if (act) {
-                    double ra = 0.0, rb = 0.0, rcc = c;
-                    auto row = [&](int j) {
-                        const double e = e_at(j), bu = bu_at(j);
-                        gv_[j] = e; Jv[j] = bu;
-                        const double s20 = fma(bu, C2R, ACR * e);
-                        const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
-                        rb = fma(rb, c, fma(ra, Q_, rcc * bu));
-                        ra = na;
-                        rcc *= A_;
-                    };
-                    if (tail) row(L - 1);
+            for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = o.aSxv[q_];
 #pragma unroll
-                    for (int j = L - 2; j >= 0; j--) row(j);
-                    M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
-                    M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
-                    M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
-                    prenorm(M);
-                }
-            } else if (act) {
-                auto f1 = [&](int j) {
-                    const bool o = (obsmask >> j) & 1u;
-                    const double e = e_at(j), bu = bu_at(j);
-                    gv_[j] = e; Jv[j] = bu;
-                    const double a00 = o ? alpha : A2;
-                    const double g = o ? C2R : 0.0;
-                    const double s20 = o ? fma(bu, C2R, ACR * e) : 0.0;
-                    if (j == 0) {
-                        M.m00 = a00; M.m01 = Q; M.m10 = g; M.m11 = 1.0; M.m20 = s20; M.m21 = bu; M.m22 = A;
-                    } else {
-                        M = pstep(a00, Q, g, s20, bu, A, M);
-                    }
-                    if ((j & 15) == 15 && j < L - 2) prenorm(M);
-                };
-#pragma unroll
-                for (int j = 0; j < L - 1; j++) f1(j);
-                if (tail) f1(L - 1);
-                prenorm(M);
-            }
-
-            // ------------------------------------------------ forward scan over the cell's LPC lanes
-            M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
-            M = pmul(M, pdpp<DPP_ROW_SHR(2), 0xF>(M));
-            M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
-            prenorm(M);
-            M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
-            if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
-            // exit state of this lane's chunk, then the entry state = exit state of the lane before
-            // (lane 0 of each half: the cell's initial state)
-            const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
-            double n_e = fma(M.m00, n_in, M.m01 * d_in);
-            double d_e = fma(M.m10, n_in, M.m11 * d_in);
-            double x_e = fma(M.m20, n_in, fma(M.m21, d_in, M.m22 * x_in));
-            n_e = dppd<DPP_WAVE_SHR1, 0xF>(n_in, n_e);
-            d_e = dppd<DPP_WAVE_SHR1, 0xF>(d_in, d_e);
-            x_e = dppd<DPP_WAVE_SHR1, 0xF>(x_in, x_e);
-            if (vl == 0) { n_e = n_in; d_e = d_in; x_e = x_in; }
-            double Xp, Vp;
-            {
-                const double rd = fast_rcp(d_e);
-                Vp = n_e * rd;
-                Xp = x_e * rd;
-            }
-
-            // ------------------------------------------------ F2: serial re-run from the exact entry
-            double sprod = 1.0, Xu = 0.0, Vu = 0.0;
-            int sexp = 0;
-            double sg = fma(C2, Vp, R);
-            double r0 = fast_rcp(sg);
-            // reverse affine composite of the lane's chunk (B1 of em_scan_impl.h), accumulated in time
-            // order while the steps are produced: (Pi, G, H) o step_j -- no second pass over h_t
-            double Pi = 1.0, G = 0.0, H = 0.0;
-            auto f2 = [&](int j) {
-                const bool o = DENSE || ((obsmask >> j) & 1u);
-                const double e = gv_[j], bu = Jv[j];       // left there by F1
-                const double r = o ? r0 : 0.0;
-                const double sl = o ? sg : 1.0;
-                sprod *= sl;
-                sneg |= __double2hiint(sl);
-                if ((j & 7) == 7) {
-                    sexp += __builtin_amdgcn_frexp_exp(sprod);
-                    sprod = __builtin_amdgcn_frexp_mant(sprod);
-                }
-                const double w = Vp * r;
-                const double K = C * w;                    // src/EM.cpp:86
-                if (DENSE) Vu = R * w;                     // :88
-                else Vu = fma(-(C2 * w), Vp, Vp);
-                const double dl = fma(-C, Xp, e);
-                Xu = fma(K, dl, Xp);                       // :87
-                likq = fma(dl * r, dl, likq);              // :122
-                const double Vp1 = fma(A2, Vu, Q);         // :76
-                const double Xp1 = fma(A, Xu, bu);         // :74
-                sg = fma(C2, Vp1, R);
-                const double z = fast_rcp(sg * Vp1);
-                const double rp1 = sg * z;
-                r0 = Vp1 * z;
-                const double AVu = A * Vu;
-                double J = AVu * rp1;                      // :100
-                double g = fma(-J, Xp1, Xu);
-                double h = fma(-J, AVu, Vu);
-                if (j >= L - 2) {
-                    // step T-1 starts the backward recursion: J = 0, g = Xu, h = Vu, zero terminal value
-                    const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
-                    J = fin ? 0.0 : J;
-                    g = fin ? Xu : g;
-                    h = fin ? Vu : h;
-                }
-                Jv[j] = J; gv_[j] = g;
-                if (j < L - 1) hs[j * 64] = h; else hlast = h;
-                G = fma(Pi, g, G);
-                H = fma(Pi * Pi, h, H);
-                Pi *= J;
-                Xp = Xp1;
-                Vp = Vp1;
-                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            };
-            if (act) {
-#pragma unroll
-                for (int j = 0; j < L - 1; j++) f2(j);
-                if (tail) f2(L - 1);
-            }
-            tLv = fma(Xu, Xu, Vu);                                                // Xs^2 + Vs at T-1 (in lastLane)
-            lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
-
-            // ------------------------------------------------ reverse scan of the chunk composites
-#define RSCAN_ROUND(n)                                                     \
-            {                                                                  \
-                const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi);                    \
-                const double Gb = dppz<DPP_ROW_SHL(n)>(G);                     \
-                const double Hb = dppz<DPP_ROW_SHL(n)>(H);                     \
-                G = fma(Pi, Gb, G);                                            \
-                H = fma(Pi * Pi, Hb, H);                                       \
-                Pi *= Pb;                                                      \
-            }
-            RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
-#undef RSCAN_ROUND
-            if constexpr (LPC == 32) {
-                // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
-                const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
-                const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
-                const int row = lane >> 4;
-                const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
-                const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
-                G = fma(Pi, Gs, G);
-                H = fma(Pi * Pi, Hs, H);
-            }
-            // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
-            // chunk is the next lane's, and the zero terminal value for the half's last lane
-            double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
-            double Vn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, H);
-            if (vl == LPC - 1) { Xn = 0.0; Vn = 0.0; }
-
-            // ------------------------------------------------ B2: serial reverse re-run + M-step sums
-            // pass 1: the recurrence (:101-102); Xs_t overwrites g_t, the variance sums are formed on
-            // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
-            // steps, the LDS reads of the series batch freely).
-            const double XnE = Xn;
-            auto b2a = [&](int j) {
-                const bool o = DENSE || ((obsmask >> j) & 1u);
-                const double J = Jv[j];
-                const double h = (j < L - 1) ? hs[j * 64] : hlast;
-                aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
-                const double Xs = fma(J, Xn, gv_[j]);       // :101
-                const double Vs = fma(J * J, Vn, h);        // :102
-                aPall += Vs;                                // :181,:183
-                if (!DENSE) aSxx += o ? Vs : 0.0;           // :152
-                gv_[j] = Xs;
-                Xn = Xs;
-                Vn = Vs;
-            };
-            auto b2b = [&](int j, bool top) {
-                const bool o = DENSE || ((obsmask >> j) & 1u);
-                const double Xs = gv_[j];
-                const double Xnx = top ? XnE : gv_[top ? j : j + 1];
-                aTx1x = fma(Xnx, Xs, aTx1x);                // :180
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) {
-                    const double ut = Uat(j, p_);           // zero at t = T-1
-                    aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
-                    aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
-                }
-                aPall = fma(Xs, Xs, aPall);
-                const double xo = o ? Xs : 0.0;
-                aSyx = fma(Yat(j), xo, aSyx);               // :151
-                if (!DENSE) aSxx = fma(xo, xo, aSxx);
-#pragma unroll
-                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
-                if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-            };
-            if (act) {
-                if (tail) b2a(L - 1);
-                else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) b2a(j);
-                if (tail) b2b(L - 1, true);
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) b2b(j, false);
-            }
-            // Xn, Vn = Xs, Vs at the first step of this lane's chunk
-            X0v = Xn; V0v = Vn;
-
+            for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = o.aTx1u[p_]; aTux[p_] = o.aTux[p_]; }
+#endif
         }
 
         // ------------------------------------------------ one reduction per half, M-step, stop rule
