@@ -172,6 +172,30 @@ def test_cells_do_not_depend_on_their_partner_or_on_the_cut(eng):
         assert np.array_equal(a["theta"][5], c["theta"][0]) and a["lik"][5] == c["lik"][0]
 
 
+def test_steady_and_fallback_cells_share_waves(eng):
+    """Fully observed series of 737..1024 steps take the steady-state sweeps when a cell's Riccati
+    recursion has converged within the first L-1 steps, the generic sweeps otherwise -- decided per
+    cell and per EM iteration.  Cells built to fail that test for many iterations (A near 1, tiny C:
+    hundreds of steps to converge), for a few (moderate A, small C) and never, interleaved so
+    that waves hold every combination: oracle parity with identical iteration counts, and results
+    bit-identical whatever the partner is."""
+    from ldsr_amd import synth
+    p, q = 1, 2
+    for T in (1000, 768, 1024, 737):
+        y, u, v = _series(T, p, q, 77 + T, "dense")
+        th0 = synth.make_init_packed(p, q, 48, seed=T)
+        th0[0::3, 0], th0[0::3, 2] = 0.97, 0.03          # A, C: slow for tens of iterations
+        th0[1::6, 0], th0[1::6, 2] = 0.80, 0.15          # a handful of iterations
+        for niter, tol in ((60, 0.0), (400, 1e-5)):
+            ref = _oracle(y, u.T[None], v.T[None], np.zeros(48), th0, niter, tol)
+            r = eng.em_batch(y, u, v, th0, niter=niter, tol=tol, algo=PAIR)
+            _check(r, ref, "steady/fallback T=%d tol=%g" % (T, tol))
+            b = eng.em_batch(y, u, v, th0[::-1].copy(), niter=niter, tol=tol, algo=PAIR)
+            assert np.array_equal(r["theta"], b["theta"][::-1]) and np.array_equal(r["lik"], b["lik"][::-1])
+            c = eng.em_batch(y, u, v, th0[3:4].copy(), niter=niter, tol=tol, algo=PAIR)
+            assert np.array_equal(r["theta"][3], c["theta"][0]) and r["lik"][3] == c["lik"][0]
+
+
 def test_results_do_not_depend_on_the_workgroup_size(eng, tmp_path):
     """Two four-wave workgroups per CU (the default where the LDS allows) against one of eight
     (LDSR_PAIR_WPB=8, read once per process -> a child process): bit-identical, static and queue."""

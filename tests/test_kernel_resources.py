@@ -35,14 +35,52 @@ def test_scan_kernel_register_budget():
 
 
 def test_pair_kernel_register_budget():
-    """The two-cells-per-wave kernels of BASELINE configs 2 (T=1000: L=32) and 5 (T=813: L=26) and
+    """The two-cells-per-wave kernels at the longest chunk without the steady-state form (L=23; from
+    L=24 on the generic sweeps of a fully observed series are a real call with its spill area: see
+    test_steady_sweeps_have_no_spill_code) and
     the four-cells-per-wave kernel of a short series, and the LEAD forms of configs 4 and 5: two waves per SIMD and no scratch (the first
     cut of the pair kernel spilled 73 VGPRs until the reverse composite moved into F2)."""
     import resource_usage
-    for tu, tmpl in (("em_pair_L32.hip", "<1, 2, 32, 32, false, false>"), ("em_pair_L32.hip", "<1, 2, 32, 32, true, false>"),
-                     ("em_pair_L26.hip", "<1, 4, 26, 32, false, false>"), ("em_quad_L13.hip", "<1, 2, 13, 16, false, false>"),
+    for tu, tmpl in (("em_pair_L23.hip", "<1, 2, 23, 32, false, false>"), ("em_pair_L23.hip", "<1, 2, 23, 32, true, false>"),
+                     ("em_pair_L23.hip", "<1, 4, 23, 32, false, false>"), ("em_quad_L13.hip", "<1, 2, 13, 16, false, false>"),
                      ("em_quad_L13.hip", "<1, 4, 13, 16, false, true>"), ("em_quad_L6.hip", "<1, 4, 6, 16, false, true>")):
         rows = resource_usage.table(os.path.join(ROOT, "ldsr_amd", "csrc", tu), tmpl)
         assert len(rows) == 1, (tu, tmpl, [r[0] for r in rows])
         _, vgpr, agpr, vspill, scratch, occ, sgpr, sspill = rows[0]
         assert (vspill, scratch) == (0, 0) and occ >= 2 and vgpr <= 256, (tu, tmpl, vgpr, vspill, scratch, occ)
+
+
+def test_steady_sweeps_have_no_spill_code():
+    """BASELINE config 2's kernel (em_pair_kernel<1, 2, 32, 32>): the steady-state sweeps of fully
+    observed series must run without scratch traffic.  The generic sweeps are their rare fallback
+    and a real call (pair_generic_sweeps_call); every spill reload of the kernel has to sit in the
+    basic block of that call.  (Inlined, the fallback's 244 registers made the allocator spill
+    values that live across the EM loop on the steady path as well: 0.84 -> 0.93 ms.)"""
+    import re
+    import subprocess
+    import tempfile
+    csrc = os.path.join(ROOT, "ldsr_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "one.hip")
+        with open(src, "w") as f:
+            f.write('#include "em_pair_impl.h"\n'
+                    'template __global__ void em_pair_kernel<1, 2, 32, 32, false, false>(EmParams);\n'
+                    'template __global__ void em_pair_kernel<1, 2, 32, 32, true, false>(EmParams);\n')
+        asm = os.path.join(td, "one.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-I" + csrc, "--offload-arch=gfx950",
+                        "--cuda-device-only", "-S", src, "-o", asm], check=True, capture_output=True)
+        text = open(asm).read()
+    kernels = re.split(r"\n(?=_Z14em_pair_kernel)", text)[1:]
+    assert len(kernels) == 2
+    for k in kernels:
+        k = k.split(".Lfunc_end")[0]
+        assert ".vgpr_count" not in k
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", k)
+        calls = [b for b in blocks if "s_swappc_b64" in b]
+        assert len(calls) == 1                                   # the fallback, nothing else
+        for b in blocks:
+            if "s_swappc_b64" in b:
+                continue
+            assert "scratch_load" not in b, b.split("\n")[0]
+    m = re.findall(r"\.vgpr_count:\s+(\d+)", text)
+    assert m and all(int(x) <= 256 for x in m)
