@@ -10,8 +10,9 @@ other BASELINE configs (cfg3 per GPU; cfg4 / cfg5 fixed grids) for DESIGN.md's t
 
 N > 1: one process per GPU.  `python bench.py --gpus N` invoked plainly starts the N ranks
 itself (a child `python -m torch.distributed.run`, before this process touches the GPU); under
-torch.distributed.run it is a rank.  Restarts shard embarrassingly -- contiguous cell ranges, no
-data-path collective (R/LDS_reconstruction.R:46 is a %dopar% over independent tasks).  The
+torch.distributed.run it is a rank.  Restarts shard embarrassingly -- every rank takes its part of
+each series' restarts (ldsr_amd/shard.py), no data-path collective (R/LDS_reconstruction.R:46 is a
+%dopar% over independent tasks).  The
 headline fields are WEAK scaling (every rank its own 4096 restarts; restart index = global
 position in the counter-based generator); for the single-series workloads the same run also
 times the STRONG split of BASELINE config 2 (4096 restarts / N per rank) and reports it in
@@ -46,7 +47,7 @@ import numpy as np  # noqa: E402
 
 # BASELINE.json configs.  cfg2 (the metric's config) and cfg3 are quoted per GPU -> weak scaling
 # (every rank gets `restarts` restarts of the one series); cfg4 / cfg5 are fixed grids "sharded
-# across the GPUs" -> strong scaling (the grid is cut into contiguous per-rank slices).
+# across the GPUs" -> strong scaling (every rank takes its part of each series' restarts).
 WORKLOADS = {
     "cfg2": dict(T=1000, p=1, q=2, series=1, restarts=4096, niter=100, scaling="weak"),
     "cfg3": dict(T=1000, p=4, q=8, series=1, restarts=8192, niter=100, scaling="weak"),
@@ -95,13 +96,12 @@ def build_problem(name, mask, world, rank, scaling=None):
         shared = 0
     off = (np.arange(S + 1) * R).astype(np.int64)
     n_global = int(off[-1])
-    lo, hi = shard.rank_slice(n_global, world, rank)
-    keep, loc = shard.local_offsets(off, lo, hi)
-    th0 = synth.make_init_packed(p, q, hi - lo, seed=1, first=lo)
-    Yk = np.ascontiguousarray(Y[keep])
-    if not shared:
-        U, V = np.ascontiguousarray(U[keep]), np.ascontiguousarray(V[keep])
-    return Yk, U, V, shared, loc, th0, n_global
+    # striped cut (ldsr_amd/shard.py): this rank's share of EVERY series' restarts; a restart's
+    # initial theta is a function of its global cell id
+    g_lo, loc = shard.rank_stripes(off, world, rank)
+    th0 = np.concatenate([synth.make_init_packed(p, q, int(loc[s_ + 1] - loc[s_]), seed=1, first=int(g_lo[s_]))
+                          for s_ in range(S)])
+    return Y, U, V, shared, loc, th0, n_global
 
 
 def bytes_per_unit(T, p, q):
@@ -368,7 +368,18 @@ def main():
         dt, units_all = reduce_over_ranks(dt, units_rank)
         return dt, units_rank, units_all, kern_ms
 
+    def units_by_rank(units_rank):
+        """E-steps every rank executed per step (the load balance of the cut)."""
+        if world == 1:
+            return [units_rank]
+        tdev = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([units_rank], dtype=torch.int64, device=tdev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return [int(x.item()) for x in parts]
+
     dt, units_rank, units_all, kern_ms = timed(job, True)
+    per_rank = units_by_rank(units_rank)
     if L.ldsr_last_em_kernel(local_rank, name_buf, 160) == 0:      # the kernel the timed launches ran
         kernel_name = name_buf.value.decode()
 
@@ -433,7 +444,9 @@ def main():
                                       args.mask if single else "paleo-style"),
                        "cells_rank0": job.cells, "cells_total": job.n_global, "niter": niter,
                        "tol": args.tol, "algo": algo_resolved, "units_per_step": units_all,
-                       "sharding": "contiguous cell ranges over %d rank(s), no collective" % world},
+                       "sharding": "rank r = the r-th of %d parts of every series' restarts, no collective" % world,
+                       "units_per_rank": per_rank,
+                       "imbalance_max_over_mean": max(per_rank) * len(per_rank) / max(sum(per_rank), 1)},
             "roofline": roof,
         }
         if strong is not None:

@@ -444,7 +444,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
         const double A2 = A * A, C2 = C * C;
         const double rR = fast_rcp(R);
-        const double C2R = C2 * rR, ACR = A * C * rR, alpha = fma(Q, C2R, A2);
+        const double C2R = C2 * rR, alpha = fma(Q, C2R, A2);
 
         // ------------------------------------------------ LEAD: the all-missing first `lead` steps
         // Over unobserved steps K_t = 0 (src/EM.cpp:82-84): Xp_{t+1} = A Xp_t + B u_t and
@@ -992,6 +992,17 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
             alive = false;
             if constexpr (QUEUE) {
+                if (abort_now) {
+                    // drain the queue: what it still holds is marked, not computed (an
+                    // LDSR_EINTERRUPTED return never leaves stale numbers that look like results)
+                    for (int pulls = 0; pulls <= nc; pulls++) {
+                        int kn = 0;
+                        if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
+                        kn = __shfl(kn, hbase, 64);
+                        if (kn >= nc) break;
+                        if (vl == 0) mark_cell_interrupted(prm, c0 + kn);
+                    }
+                }
                 if (!abort_now) {
                     int kn = 0;
                     if (vl == 0) kn = atomicAdd(prm.queue + s, 1);

@@ -306,9 +306,21 @@ __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_S
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
-__device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
+__device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
-                                             int s, int cell, int lane, int wv, int nl, int rp);
+                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit);
+
+// A cell the work queue handed out after the host raised the interrupt flag: not computed, but
+// marked, so that an LDSR_EINTERRUPTED return never leaves stale numbers that look like results.
+__device__ __forceinline__ void mark_cell_interrupted(const EmParams &prm, int cell) {
+    const int P = 6 + prm.p + prm.q;
+    for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+    if (prm.liks && prm.liks_nanfill)
+        for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+    prm.n_iter[cell] = 0;
+    prm.lik[cell] = NAN;
+    prm.status[cell] = 3;
+}
 
 // QUEUE = waves pull cells from the per-series work queue (cells converge at different
 // iterations); !QUEUE = wave w of block b owns cell c0 + w (every cell runs exactly niter
@@ -342,11 +354,16 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
     // global image: buffer resource over the series image (out-of-range reads return 0)
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gimg, 0, (int)(IMG * sizeof(double)), 0x00020000);
     const bool dense = prm.sc[s].n_obs == T && !FIT && W == 1;   // FIT / multi-wave: generic path only
+    // The host's interrupt flag is polled every 64 EM iterations OF THE WAVE GROUP (not of the
+    // cell: cells that converge in fewer would never poll); once it is seen, the group computes
+    // nothing more and marks whatever the queue still hands it.
+    int wit = 0;
+    bool aborted = false;
     if constexpr (W > 1) {
         // one group: every wave of the workgroup works on the same cell
         int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
         if constexpr (!QUEUE) {
-            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0, lane, wave, nl, rp);
+            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0, lane, wave, nl, rp, wit);
         } else {
             for (int pulls = 0; pulls <= nc; pulls++) {
                 if (threadIdx.x == 0) *qslot = atomicAdd(prm.queue + s, 1);
@@ -354,15 +371,16 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
                 const int k = __builtin_amdgcn_readfirstlane(*(volatile int *)qslot);
                 __syncthreads();              // everyone has read the slot before the next pull
                 if (k >= nc) break;
-                em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, wave, nl, rp);
+                if (aborted) { if (threadIdx.x == 0) mark_cell_interrupted(prm, c0 + k); continue; }
+                aborted = em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, wave, nl, rp, wit);
             }
         }
     } else if constexpr (!QUEUE) {
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
         if (dense)
-            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
         else
-            em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp);
+            em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
     } else {
         // Work queue: every wave pulls cells of this series until the counter passes the
         // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
@@ -374,18 +392,19 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
             if (lane == 0) k = atomicAdd(prm.queue + s, 1);
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
+            if (aborted) { if (lane == 0) mark_cell_interrupted(prm, c0 + k); continue; }
             if (dense)
-                em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp);
+                aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
             else
-                em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp);
+                aborted = em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
         }
     }
 }
 
 template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
-__device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *ys,
+__device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
-                                             int s, int cell, int lane, int wv, int nl, int rp) {
+                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit) {
     constexpr int NL = 64 * W;
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
@@ -453,7 +472,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
                         if (prm.fitJ) prm.fitJ[o] = NAN;
                     }
         }
-        return;
+        return false;
     }
 
     white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
@@ -937,7 +956,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
             S.V0 = readlane_d(Vs, 0);                  // :219
             bool neg = __any(sneg < 0);                // log of a negative Sigma in the reference
             int abort_now = 0;
-            if (!FIT && prm.abort && ((it + 1) & 63) == 0) {
+            if (!FIT && prm.abort && ((++wit) & 63) == 0) {
                 // every wave of a multi-wave cell must see the SAME value (barrier counts):
                 // wave 0 polls, the flag travels with the sums record
                 if (wv == 0) abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
@@ -1022,6 +1041,7 @@ __device__ __forceinline__ void em_scan_cell(const EmParams &prm, const double *
         prm.lik[cell] = lik;
         prm.status[cell] = (interrupted && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
     }
+    return interrupted;
 }
 
 // Launch plan of a (T, PP, QQ) shape: chunk length, waves per cell, cells per workgroup, and

@@ -92,7 +92,9 @@ struct IntrScope {
     }
     ~IntrScope() {
         if (!owner) return;
-        g_intr.active.fetch_sub(1);
+        // the last external call to leave clears the flag: a raised interrupt stops every call that
+        // is in flight and is over once they have all returned
+        if (g_intr.active.fetch_sub(1) == 1 && g_intr.flag) *(volatile int *)g_intr.flag = 0;
         t_poll = false;
     }
 };
@@ -617,7 +619,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 void *d_workspace, size_t workspace_bytes,
                                 const int *abort_flag = nullptr, int dense_hint = -1,
                                 int *algo_used = nullptr, int lead_hint = -1, int *lead_used = nullptr,
-                                int lead_force = 0) {
+                                int lead_force = 0, const int *plan_off = nullptr, int plan_ns = 0) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -641,7 +643,10 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         if (!em_pair_supported(Te, PP, QQ, lp)) return false;
         const int c = (64 / lp) * 8;          // a CU's eight waves
         long wgs = 0;
-        for (int s = 0; s < n_series; s++) wgs += (cell_offsets[s + 1] - cell_offsets[s] + c - 1) / c;
+        // (a slice of a multi-device call counts the whole call's cells: plan_off)
+        const int *po = plan_off ? plan_off : cell_offsets;
+        const int pn = plan_off ? plan_ns : n_series;
+        for (int s = 0; s < pn; s++) wgs += (po[s + 1] - po[s] + c - 1) / c;
         const long cus = device_cu_count(device);
         if (force_fill()) return true;
         if (!lead_form && em_pair_waves_per_block(Te, PP, QQ, lp, 0) == 4)
@@ -928,6 +933,14 @@ struct Slice {
     double tol = 0.0;
     const double *y = nullptr, *u = nullptr, *v = nullptr, *theta0 = nullptr;
     std::vector<int> off;
+    // Striped cut (make_slices): the slice holds EVERY series of the call and, of series s, the
+    // cells [g_lo[s], g_lo[s] + off[s+1] - off[s]) of the caller's arrays -- theta0 / theta / lik /
+    // n_iter / status / liks are the caller's whole arrays, gathered and scattered per series.
+    std::vector<int> g_lo;
+    // AUTO looks at the whole call, not at the slice: the kernel (hence the rounding of the results)
+    // must not depend on how many devices share the work
+    const int *plan_off = nullptr;
+    int plan_ns = 0;
     // host outputs of phase 1 (liks optional: the full [n_cells][niter] trace, NaN padded)
     double *theta = nullptr, *lik = nullptr, *liks = nullptr;
     int *n_iter = nullptr, *status = nullptr;
@@ -985,6 +998,19 @@ static WinLayout win_layout(int n, int P, int T, int niter) {
     W.out_bytes = c.o - W.out_begin;
     W.total = c.o;
     return W;
+}
+
+// per-cell results of the slice (pinned block `pout`) -> the caller's arrays, series by series
+static void slice_scatter(const Slice &S, const char *pout) {
+    const int P = S.P;
+    for (int s = 0; s < S.n_series; s++) {
+        const size_t lo = (size_t)S.off[(size_t)s], nc = (size_t)S.off[(size_t)s + 1] - lo, g = (size_t)S.g_lo[(size_t)s];
+        if (!nc) continue;
+        memcpy(S.theta + g * P, pout + (S.d_theta - S.d_out) + sizeof(double) * lo * P, sizeof(double) * nc * P);
+        memcpy(S.lik + g, pout + (S.d_lik - S.d_out) + sizeof(double) * lo, sizeof(double) * nc);
+        memcpy(S.n_iter + g, pout + (S.d_nit - S.d_out) + sizeof(int) * lo, sizeof(int) * nc);
+        memcpy(S.status + g, pout + (S.d_st - S.d_out) + sizeof(int) * lo, sizeof(int) * nc);
+    }
 }
 
 static int slice_run(Slice &S) {
@@ -1054,7 +1080,10 @@ static int slice_run(Slice &S) {
     }
     if (S.u) memcpy(pin + (S.d_u - S.d_in), S.u, sizeof(double) * nuv * T * S.p);
     if (S.v) memcpy(pin + (S.d_v - S.d_in), S.v, sizeof(double) * nuv * T * S.q);
-    memcpy(pin + (S.d_th0 - S.d_in), S.theta0, sizeof(double) * (size_t)n * P);
+    for (int s = 0; s < S.n_series; s++)      // this slice's cells of every series
+        memcpy(pin + (S.d_th0 - S.d_in) + sizeof(double) * (size_t)S.off[(size_t)s] * P,
+               S.theta0 + (size_t)S.g_lo[(size_t)s] * P,
+               sizeof(double) * (size_t)(S.off[(size_t)s + 1] - S.off[(size_t)s]) * P);
     memcpy(pin + (S.d_off - S.d_in), S.off.data(), sizeof(int) * ((size_t)S.n_series + 1));
     HIPCHK(hipMemcpyAsync(A->dev + S.d_in, pin, S.in_bytes, hipMemcpyHostToDevice, A->stream));
 
@@ -1065,7 +1094,7 @@ static int slice_run(Slice &S) {
         (double *)(A->dev + S.d_theta), (double *)(A->dev + S.d_lik), (int *)(A->dev + S.d_nit),
         (int *)(A->dev + S.d_st), S.trace_on_device ? (double *)(A->dev + S.d_liks) : nullptr,
         S.liks != nullptr, A->dev + S.d_ws, S.wsb, intr_flag_for_kernels(), S.dense_hint, &S.algo_used,
-        S.lead_hint, &S.lead_used);
+        S.lead_hint, &S.lead_used, 0, S.plan_off, S.plan_ns);
     if (rc) return rc;
     char *pout = A->pin + S.p_out;
     if (S.fuse && S.trace_on_device) {
@@ -1113,12 +1142,7 @@ static int slice_run(Slice &S) {
                               A->stream));
         HIPCHK(wait_stream(A->stream));
         if (intr_raised()) return fail(LDSR_EINTERRUPTED, "interrupted by the caller's interrupt callback");
-        if (S.want_all) {
-            memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
-            memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
-            memcpy(S.n_iter, pout + (S.d_nit - S.d_out), sizeof(int) * (size_t)n);
-            memcpy(S.status, pout + (S.d_st - S.d_out), sizeof(int) * (size_t)n);
-        }
+        if (S.want_all) slice_scatter(S, pout);
         const double nan = std::numeric_limits<double>::quiet_NaN();
         memcpy(S.h_winner, pw + W.cell, sizeof(int) * ns);
         memcpy(S.h_theta_w, pw + W.theta, sizeof(double) * (size_t)ns * P);
@@ -1139,12 +1163,15 @@ static int slice_run(Slice &S) {
     }
     HIPCHK(hipMemcpyAsync(pout, A->dev + S.d_out, S.out_bytes, hipMemcpyDeviceToHost, A->stream));
     HIPCHK(wait_stream(A->stream));
-    memcpy(S.theta, pout + (S.d_theta - S.d_out), sizeof(double) * (size_t)n * P);
-    memcpy(S.lik, pout + (S.d_lik - S.d_out), sizeof(double) * (size_t)n);
-    memcpy(S.n_iter, pout + (S.d_nit - S.d_out), sizeof(int) * (size_t)n);
-    memcpy(S.status, pout + (S.d_st - S.d_out), sizeof(int) * (size_t)n);
-    if (S.liks)     // the full trace goes straight to the caller's (pageable) array
-        HIPCHK(hipMemcpy(S.liks, A->dev + S.d_liks, trace_bytes, hipMemcpyDeviceToHost));
+    slice_scatter(S, pout);
+    if (S.liks)     // the full trace goes straight to the caller's (pageable) array, series by series
+        for (int s = 0; s < S.n_series; s++) {
+            const size_t nc = (size_t)(S.off[(size_t)s + 1] - S.off[(size_t)s]);
+            if (nc)
+                HIPCHK(hipMemcpy(S.liks + (size_t)S.g_lo[(size_t)s] * S.niter,
+                                 A->dev + S.d_liks + sizeof(double) * (size_t)S.off[(size_t)s] * S.niter,
+                                 sizeof(double) * nc * S.niter, hipMemcpyDeviceToHost));
+        }
     return LDSR_OK;
 }
 
@@ -1220,52 +1247,37 @@ static int slice_fit_winners(Slice &S, int n_w, const int *w_series, const int *
     return LDSR_OK;
 }
 
-// cut [0, n_cells) into n_devices contiguous slices and describe each
+// Cut the cell grid over the devices BY SERIES: device d gets the d-th of n_devices contiguous
+// parts of EVERY series' restarts.  Series differ a lot in iterations to converge (config 5: 34 k
+// to 130 k E-steps per series), so contiguous ranges of the flattened grid -- round 2's cut -- left
+// the devices up to 1.32x apart at eight; the reference hands each restart to whichever worker is
+// idle (R/LDS_reconstruction.R:46), and restarts of one series are statistically alike, so equal
+// shares of every series are equal shares of the work (1.004 / 1.007 / 1.012 at 2 / 4 / 8 on the
+// same grid; tests/test_shard_gloo.py pins the bound).  Every slice carries all series (<= 100 KB
+// each) and the whole call's offsets for AUTO's plan.
 static void make_slices(std::vector<Slice> &sl, int n_devices, const int *devices, int n_series,
                         int T, int p, int q, const double *y, const double *u, const double *v,
                         int shared_uv, const int *cell_offsets, const double *theta0, int niter,
                         double tol, int algo, double *theta, double *lik, int *n_iter,
-                        int *status, double *liks, std::vector<int> &lo_of, std::vector<int> &s0_of) {
-    const int n_cells = cell_offsets[n_series];
-    const int P = 6 + p + q;
+                        int *status, double *liks) {
     sl.resize((size_t)n_devices);
-    lo_of.assign((size_t)n_devices + 1, n_cells);
-    s0_of.assign((size_t)n_devices, 0);
     for (int d = 0; d < n_devices; d++) {
-        const int lo = (int)((long long)n_cells * d / n_devices);
-        const int hi = (int)((long long)n_cells * (d + 1) / n_devices);
-        lo_of[(size_t)d] = lo;
         Slice &S = sl[(size_t)d];
         S.device = devices[d];
         S.T = T; S.p = p; S.q = q; S.shared_uv = shared_uv; S.niter = niter; S.tol = tol; S.algo = algo;
-        if (hi <= lo) {
-            S.n_series = 0;
-            S.off.assign(1, 0);
-            continue;
+        S.off.assign((size_t)n_series + 1, 0);
+        S.g_lo.assign((size_t)n_series, 0);
+        for (int s = 0; s < n_series; s++) {
+            const long long a = cell_offsets[s], ns = cell_offsets[s + 1] - cell_offsets[s];
+            const int lo = (int)(a + ns * d / n_devices), hi = (int)(a + ns * (d + 1) / n_devices);
+            S.g_lo[(size_t)s] = lo;
+            S.off[(size_t)s + 1] = S.off[(size_t)s] + (hi - lo);
         }
-        // series range [s0, s1) that owns cells [lo, hi), and the clipped local offsets
-        int s0 = 0;
-        while (cell_offsets[s0 + 1] <= lo) s0++;
-        int s1 = s0;
-        while (s1 < n_series && cell_offsets[s1] < hi) s1++;
-        s0_of[(size_t)d] = s0;
-        S.n_series = s1 - s0;
-        S.off.resize((size_t)(s1 - s0) + 1);
-        for (int s = s0; s <= s1; s++) {
-            int c = cell_offsets[s];
-            c = c < lo ? lo : (c > hi ? hi : c);
-            S.off[(size_t)(s - s0)] = c - lo;
-        }
-        const size_t uo = shared_uv ? 0 : (size_t)s0 * T * p, vo = shared_uv ? 0 : (size_t)s0 * T * q;
-        S.y = y + (size_t)s0 * T;
-        S.u = u ? u + uo : nullptr;
-        S.v = v ? v + vo : nullptr;
-        S.theta0 = theta0 + (size_t)lo * P;
-        S.theta = theta + (size_t)lo * P;
-        S.lik = lik + lo;
-        S.n_iter = n_iter + lo;
-        S.status = status + lo;
-        S.liks = liks ? liks + (size_t)lo * niter : nullptr;
+        S.n_series = S.off[(size_t)n_series] > 0 ? n_series : 0;
+        S.y = y; S.u = u; S.v = v;
+        S.theta0 = theta0;
+        S.theta = theta; S.lik = lik; S.n_iter = n_iter; S.status = status; S.liks = liks;
+        if (n_devices > 1) { S.plan_off = cell_offsets; S.plan_ns = n_series; }
     }
 }
 
@@ -1313,9 +1325,8 @@ extern "C" int ldsr_em_batch_multi(int n_devices, const int *devices, int n_seri
     if (cell_offsets[n_series] == 0) return LDSR_OK;
     IntrScope intr;
     std::vector<Slice> sl;
-    std::vector<int> lo_of, s0_of;
     make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
-                niter, tol, algo, theta, lik, n_iter, status, liks, lo_of, s0_of);
+                niter, tol, algo, theta, lik, n_iter, status, liks);
     return run_slices(sl);
 }
 
@@ -1363,9 +1374,8 @@ extern "C" int ldsr_em_restart_grid(int n_devices, const int *devices, int n_ser
         if (!status_all) { t_st.resize((size_t)n_cells + 1); status_all = t_st.data(); }
     }
     std::vector<Slice> sl;
-    std::vector<int> lo_of, s0_of;
     make_slices(sl, n_devices, devices, n_series, T, p, q, y, u, v, shared_uv, cell_offsets, theta0,
-                niter, tol, algo, theta_all, lik_all, n_iter_all, status_all, nullptr, lo_of, s0_of);
+                niter, tol, algo, theta_all, lik_all, n_iter_all, status_all, nullptr);
     for (Slice &S : sl) S.max_winners = S.n_series;
     if (fused) {
         Slice &S = sl[0];
@@ -1408,14 +1418,15 @@ extern "C" int ldsr_em_restart_grid(int n_devices, const int *devices, int n_ser
     for (size_t d = 0; d < sl.size(); d++) {
         Slice &S = sl[d];
         if (S.n_series == 0) continue;
-        const int lo = lo_of[d], hi = lo_of[d + 1], s0 = s0_of[d];
         std::vector<int> ws_, wc_, gs_;
-        for (int s = s0; s < s0 + S.n_series; s++)
-            if (winner[s] >= lo && winner[s] < hi) {
-                ws_.push_back(s - s0);
-                wc_.push_back(winner[s] - lo);
+        for (int s = 0; s < S.n_series; s++) {
+            const int lo = S.g_lo[(size_t)s], nc = S.off[(size_t)s + 1] - S.off[(size_t)s];
+            if (winner[s] >= lo && winner[s] < lo + nc) {
+                ws_.push_back(s);
+                wc_.push_back(S.off[(size_t)s] + winner[s] - lo);
                 gs_.push_back(s);
             }
+        }
         const int n_w = (int)ws_.size();
         if (!n_w) continue;
         std::vector<double> b_liks, b_X, b_Y, b_V, b_J;
@@ -1502,7 +1513,9 @@ static int run_fit_kernel(int mode, int device, int n_series, int T, int p, int 
     rc = arena_acquire(device, &lease.a);
     if (rc) return rc;
     Arena *A = lease.a;
-    const WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, LDSR_ALGO_SCAN, 1);
+    WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, LDSR_ALGO_SCAN, 1);
+    L.img2_stride = 0;       // no pair-family launch here: series_prep builds the scan image only
+    L.img3_stride = 0;
     // the serial smoother uses X / V as its filtered-state strip; the scan FIT kernel needs none
     const bool need_strip = !(mode == 0 || mode == 3) || !em_scan_supported(T, PP, QQ);
     Carver c;

@@ -1,32 +1,47 @@
 """Sharding of the (series / fold, restart) cell grid over the GPUs of one node.
 
-Cells never communicate during EM (the reference runs them as independent foreach tasks,
-R/LDS_reconstruction.R:46), so the grid is cut into contiguous ranges, one per rank, and the
-only cross-rank step is the gather of 8*(P+3) bytes per cell before the per-series argmax
-(R/LDS_reconstruction.R:50-58).  No data-path collective; the gather uses whatever
-torch.distributed backend the caller initialised (RCCL on GPUs, gloo in the CPU tests)."""
+Cells never communicate during EM (the reference runs them as independent foreach tasks handed
+to whichever worker is idle, R/LDS_reconstruction.R:46), so the grid is cut with no data-path
+collective: rank r owns the r-th of `world` contiguous parts of EVERY series' restarts.  Series
+differ a lot in iterations to converge (BASELINE config 5: 34 k to 130 k E-steps per series), while
+the restarts of one series are statistically alike -- so equal shares of every series are equal
+shares of the work (max / mean E-steps per rank 1.004 / 1.007 / 1.012 at 2 / 4 / 8 ranks on config 5,
+against 1.18 / 1.22 / 1.32 for contiguous ranges of the flattened grid, round 2's cut).  Every rank
+holds every series (<= 100 KB each).  The only cross-rank step is the gather of 8*(P+3) bytes per
+cell before the per-series argmax (R/LDS_reconstruction.R:50-58); it uses whatever
+torch.distributed backend the caller initialised (RCCL on GPUs, gloo in the CPU tests).  The
+library cuts the same way for callers without torch.distributed (make_slices, ldsr_api.hip)."""
 import numpy as np
 
 
 def rank_slice(n_cells, world, rank):
-    """Contiguous range [lo, hi) of the flattened cell grid owned by `rank`."""
+    """Contiguous range [lo, hi): the rank's part of ONE series' n_cells restarts."""
     lo = n_cells * rank // world
     hi = n_cells * (rank + 1) // world
     return lo, hi
 
 
-def local_offsets(cell_offsets, lo, hi):
-    """Clip the per-series cell ranges to [lo, hi): returns (series ids present, local
-    cell_offsets starting at 0)."""
+def rank_stripes(cell_offsets, world, rank):
+    """The rank's cells of every series: (g_lo [S], local offsets [S+1]) -- of series s the rank
+    owns the global cells [g_lo[s], g_lo[s] + loc[s+1] - loc[s]), stored locally from loc[s]."""
     off = np.asarray(cell_offsets, dtype=np.int64)
     S = off.size - 1
-    starts = np.clip(off[:-1], lo, hi)
-    ends = np.clip(off[1:], lo, hi)
-    keep = [s for s in range(S) if ends[s] > starts[s]]
-    loc = np.zeros(len(keep) + 1, dtype=np.int32)
-    for i, s in enumerate(keep):
-        loc[i + 1] = loc[i] + (ends[s] - starts[s])
-    return np.asarray(keep, dtype=np.int64), loc
+    g_lo = np.empty(S, dtype=np.int64)
+    loc = np.zeros(S + 1, dtype=np.int32)
+    for s in range(S):
+        lo, hi = rank_slice(int(off[s + 1] - off[s]), world, rank)
+        g_lo[s] = off[s] + lo
+        loc[s + 1] = loc[s] + (hi - lo)
+    return g_lo, loc
+
+
+def stripe_index(cell_offsets, world, rank):
+    """Global cell ids of the rank's cells, in local order."""
+    g_lo, loc = rank_stripes(cell_offsets, world, rank)
+    if loc[-1] == 0:
+        return np.zeros(0, dtype=np.int64)
+    return np.concatenate([np.arange(g_lo[s], g_lo[s] + loc[s + 1] - loc[s], dtype=np.int64)
+                           for s in range(g_lo.size)])
 
 
 def em_batch_sharded(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, compute=None,
@@ -44,13 +59,13 @@ def em_batch_sharded(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, c
     theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
     n, P = theta0.shape
     Y = np.asarray(y, dtype=np.float64)
-    multi = Y.ndim == 2 and Y.shape[0] > 1
     if cell_offsets is None:
         cell_offsets = [0, n]
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    lo, hi = rank_slice(n, world, rank)
-    keep, loc = local_offsets(cell_offsets, lo, hi)
+    idx = stripe_index(cell_offsets, world, rank)          # this rank's cells, local order
+    _, loc = rank_stripes(cell_offsets, world, rank)
+    n_loc = idx.size
 
     if compute is None:
         from . import api
@@ -59,30 +74,21 @@ def em_batch_sharded(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, c
         def compute(y_, u_, v_, th_, **k):
             return api.em_batch(y_, u_, v_, th_, device=dev, **k)
 
-    def take(a, name):
-        if a is None:
-            return None
-        a = np.asarray(a, dtype=np.float64)
-        if a.ndim == 3:
-            return a[keep]
-        return a
-
-    res = {"theta": np.empty((hi - lo, P)), "lik": np.empty(hi - lo),
-           "n_iter": np.empty(hi - lo, np.int32), "status": np.empty(hi - lo, np.int32)}
-    if hi > lo:
-        y_loc = Y[keep] if multi else Y
-        r = compute(y_loc, take(u, "u"), take(v, "v"), theta0[lo:hi], cell_offsets=loc,
-                    niter=niter, tol=tol, **kw)
+    res = {"theta": np.empty((n_loc, P)), "lik": np.empty(n_loc),
+           "n_iter": np.empty(n_loc, np.int32), "status": np.empty(n_loc, np.int32)}
+    if n_loc:
+        r = compute(Y, u, v, theta0[idx], cell_offsets=loc, niter=niter, tol=tol, **kw)
         for k_ in res:
             res[k_][...] = r[k_]
     if world == 1:
         return res
 
-    # gather: pack (theta | lik | n_iter | status) rows, pad to the largest slice
+    # gather: pack (theta | lik | n_iter | status) rows, pad to the largest share
     rows = np.concatenate([res["theta"], res["lik"][:, None],
                            res["n_iter"][:, None].astype(np.float64),
                            res["status"][:, None].astype(np.float64)], axis=1)
-    max_rows = max(rank_slice(n, world, r_)[1] - rank_slice(n, world, r_)[0] for r_ in range(world))
+    sizes = [stripe_index(cell_offsets, world, r_).size for r_ in range(world)]
+    max_rows = max(max(sizes), 1)
     backend = dist.get_backend(group)
     tdev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = torch.zeros((max_rows, P + 3), dtype=torch.float64, device=tdev)
@@ -91,8 +97,7 @@ def em_batch_sharded(y, u, v, theta0, cell_offsets=None, niter=1000, tol=1e-5, c
     dist.all_gather(parts, buf, group=group)
     out = np.empty((n, P + 3))
     for r_ in range(world):
-        a, b = rank_slice(n, world, r_)
-        out[a:b] = parts[r_][:b - a].cpu().numpy()
+        out[stripe_index(cell_offsets, world, r_)] = parts[r_][:sizes[r_]].cpu().numpy()
     return {"theta": out[:, :P].copy(), "lik": out[:, P].copy(),
             "n_iter": out[:, P + 1].astype(np.int32), "status": out[:, P + 2].astype(np.int32)}
 

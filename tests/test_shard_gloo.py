@@ -93,15 +93,43 @@ def test_two_rank_gloo_matches_single_process():
         assert off[s] <= win[s] < off[s + 1]
 
 
-def test_rank_slices_cover_grid_exactly():
+def test_stripes_cover_grid_exactly():
     from ldsr_amd import shard
-    for n in (0, 1, 7, 4096, 24576):
+    for off in ([0, 0], [0, 1], [0, 7], [0, 5, 5, 9, 12], [0, 512, 1024, 1536], [0, 3, 4, 4, 20]):
+        n = off[-1]
         for world in (1, 2, 3, 8):
-            edges = [shard.rank_slice(n, world, r) for r in range(world)]
-            assert edges[0][0] == 0 and edges[-1][1] == n
-            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
-    keep, loc = shard.local_offsets([0, 5, 5, 9, 12], 3, 10)
-    assert keep.tolist() == [0, 2, 3] and loc.tolist() == [0, 2, 6, 7]
+            seen = np.concatenate([shard.stripe_index(off, world, r) for r in range(world)])
+            assert sorted(seen.tolist()) == list(range(n))
+            for r in range(world):
+                g_lo, loc = shard.rank_stripes(off, world, r)
+                assert loc[0] == 0 and loc[-1] == shard.stripe_index(off, world, r).size
+                for s in range(len(off) - 1):         # a contiguous part of the series, inside it
+                    assert off[s] <= g_lo[s] <= g_lo[s] + loc[s + 1] - loc[s] <= off[s + 1]
+    g_lo, loc = shard.rank_stripes([0, 5, 7, 13], 2, 1)
+    assert g_lo.tolist() == [2, 6, 10] and loc.tolist() == [0, 3, 4, 7]
+
+
+def test_striped_cut_balances_converged_config5():
+    """BASELINE config 5 run to convergence (CPU oracle, niter=1000, tol=1e-5): series need 34 k to
+    130 k E-steps each, so contiguous ranges of the flattened grid (round 2's cut) leave the ranks
+    1.18 / 1.22 / 1.32 apart at 2 / 4 / 8; the striped cut must stay within 5 %."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from ldsr_amd import shard
+    from oracle import oracle as O
+    Y, U, V, shared, off, th0, n = bench.build_problem("cfg5", "dense", 1, 0)
+    S = Y.shape[0]
+    keep = np.concatenate([np.arange(off[s], off[s] + 128) for s in range(S)])    # 128 of the 512 restarts per series
+    soc = np.repeat(np.arange(S), 128).astype(np.int32)
+    _, _, nit, _ = O.em_batch(Y, U, V, soc, th0[keep], 1000, 1e-5, n_threads=os.cpu_count() or 8)
+    loc_off = np.arange(S + 1) * 128
+    worst_old = 0.0
+    for world in (2, 4, 8):
+        per = [nit[shard.stripe_index(loc_off, world, r)].sum() for r in range(world)]
+        assert max(per) * world / sum(per) <= 1.05, (world, per)
+        old = [nit[lo:hi].sum() for lo, hi in (shard.rank_slice(nit.size, world, r) for r in range(world))]
+        worst_old = max(worst_old, max(old) * world / sum(old))
+    assert worst_old > 1.15        # what the contiguous cut did on the same grid
 
 
 def _gpu_worker(rank, world, port, q_out):
