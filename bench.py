@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0; see the task contract for the fields.  Extra obj
                 --pmc passes of this same command (profiles/pmc_summary.json) and are emitted
                 only when an entry for this workload AND this kernel instantiation exists.
   cpu_baseline  the CPU oracle (a port of src/EM.cpp, not RcppArmadillo) on the host cores
+  verified      a 64-cell sample of the last timed launch against the CPU oracle (outside the
+                timed region): identical iteration counts, theta and lik within the parity bar
 """
 import argparse
 import ctypes as C
@@ -205,6 +207,38 @@ def cpu_baseline(p, q, niter, Y, U, V, seed, target_s=12.0):
                       % (cells, niter, cores, dt)}
 
 
+def verify_sample(job, p, q, niter, tol, n_sample=64):
+    """Outside the timed region: what the LAST timed launch left in HBM against the CPU oracle on
+    a sample of its cells (evenly spaced over the rank's grid) -- identical iteration counts, then
+    theta and lik within 1e-6 relative + 1e-9 absolute.  The oracle is the
+    checker here, as in tests/ (the full-size check of this same launch is
+    tests/test_gpu_full_configs.py::test_bench_launch_matches_oracle)."""
+    from oracle import oracle as O
+    th = job.d_th.cpu().numpy()
+    lik = job.d_lik.cpu().numpy()
+    nit = job.d_nit.cpu().numpy()
+    Y, U, V = job.d_y.cpu().numpy(), job.d_u.cpu().numpy(), job.d_v.cpu().numpy()
+    S = Y.shape[0]
+    if U.shape[0] != S:
+        U, V = np.repeat(U, S, axis=0), np.repeat(V, S, axis=0)
+    n = th.shape[0]
+    idx = np.unique(np.linspace(0, n - 1, min(n_sample, n)).astype(np.int64))
+    soc = (np.searchsorted(job.loc_off, idx, side="right") - 1).astype(np.int32)
+    th0 = job.d_th0.cpu().numpy()[idx]
+    r_th, r_lik, r_nit, _ = O.em_batch(Y, U, V, soc, th0, niter, tol, n_threads=host_cores())
+    same_it = bool(np.array_equal(r_nit, nit[idx]))
+    fin = np.isfinite(r_lik)
+    d_th = np.abs(th[idx] - r_th)[fin]
+    d_lk = np.abs(lik[idx] - r_lik)[fin]
+    bar_th = (1e-6 * np.abs(r_th) + 1e-9)[fin]
+    bar_lk = (1e-6 * np.abs(r_lik) + 1e-9)[fin]
+    ok = same_it and bool(np.all(d_th <= bar_th)) and bool(np.all(d_lk <= bar_lk))
+    rel = float(max((d_th / bar_th).max(), (d_lk / bar_lk).max())) if d_th.size else 0.0
+    return {"cells": int(idx.size), "against": "CPU oracle (port of src/EM.cpp), same niter / tol",
+            "n_iter_equal": same_it, "max_dev_over_bar": rel,
+            "bar": "|d| <= 1e-6 |ref| + 1e-9 on every theta entry and on lik", "ok": ok}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` invoked plainly: start the N ranks as a CHILD
     `python -m torch.distributed.run` (this parent never imports torch or touches the GPU, and
@@ -227,6 +261,7 @@ class Job:
     def __init__(self, L, torch, dev, local_rank, prob, T, p, q, niter, tol, algo):
         from ldsr_amd import _lib
         Y, U, V, self.shared_uv, loc_off, th0, self.n_global = prob
+        self.loc_off = np.asarray(loc_off, dtype=np.int64)
         self.S, self.cells = Y.shape[0], th0.shape[0]
         self.d_y = torch.from_numpy(Y).to(dev)          # [S][T]
         self.d_u = torch.from_numpy(U).to(dev)          # [S or 1][T][p]
@@ -286,6 +321,8 @@ def main():
                     help="headline split of a single-series workload over the ranks (default weak: "
                          "the per-GPU configuration of BASELINE.json; strong: its restarts / N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of a 64-cell sample of the last timed launch")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -451,6 +488,11 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
+        if not args.no_verify:
+            out["verified"] = verify_sample(job, p, q, niter, args.tol)
+            if not out["verified"]["ok"]:
+                print(json.dumps(out), flush=True)
+                sys.exit("bench.py: the timed launch does not match the CPU oracle")
         if world == 1 and not args.no_cpu_baseline:
             Y, U, V = (job.d_y.cpu().numpy(), job.d_u.cpu().numpy(), job.d_v.cpu().numpy())
             out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)
