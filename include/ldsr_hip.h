@@ -239,6 +239,17 @@ int ldsr_profile_collect(double *total_ms, int *n_launches);
 /* Restart selection on the host: index of the winning cell among n, or -1. */
 int ldsr_select_restart(int n, const double *lik, const double *theta, int p, int q);
 
+/* The reference's five skill metrics (/root/reference/src/utils.cpp: NSE :13, nRMSE :36, corr :49,
+ * KGE :68, RE :93; .Call entries _ldsr_NSE .. _ldsr_RE, src/RcppExports.cpp:71-130,137-141).  Host
+ * code on n points -- cross-validation folds of 12..46 values: they are here because a DLL that
+ * replaces ldsr.so must keep them registered, not because they are hot.  Same argument order as
+ * the reference: model output first, observation second. */
+double ldsr_metric_nse(int n, const double *yhat, const double *y);
+double ldsr_metric_nrmse(int n, const double *yhat, const double *y, double norm_const);
+double ldsr_metric_corr(int n, const double *x, const double *y);
+double ldsr_metric_kge(int n, const double *yhat, const double *y);
+double ldsr_metric_re(int n, const double *yhat, const double *y, double yc_bar);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,11 @@ SIGNATURES = {
     "ldsr_profile_enable": (None, [C.c_int]),
     "ldsr_profile_collect": (C.c_int, [_dp, _ip]),
     "ldsr_select_restart": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int]),
+    "ldsr_metric_nse": (C.c_double, [C.c_int, _dp, _dp]),
+    "ldsr_metric_nrmse": (C.c_double, [C.c_int, _dp, _dp, C.c_double]),
+    "ldsr_metric_corr": (C.c_double, [C.c_int, _dp, _dp]),
+    "ldsr_metric_kge": (C.c_double, [C.c_int, _dp, _dp]),
+    "ldsr_metric_re": (C.c_double, [C.c_int, _dp, _dp, C.c_double]),
 }
 
 

@@ -162,8 +162,12 @@ int R_useDynamicSymbols(DllInfo *dll, int v) { (void)dll; return v; }
 void R_init_ldsrhip(DllInfo *dll);
 void R_unload_ldsrhip(DllInfo *dll);
 
+void R_init_ldsr(DllInfo *dll);
+void R_unload_ldsr(DllInfo *dll);
 int rmock_init(void) { R_init_ldsrhip(NULL); return g_table != NULL; }
 void rmock_unload(void) { R_unload_ldsrhip(NULL); }
+/* the same object loaded under the name ldsr.so: R would call R_init_ldsr */
+int rmock_init_as_ldsr(void) { R_init_ldsr(NULL); return g_table != NULL; }
 int rmock_n_routines(void) { int n = 0; while (g_table && g_table[n].name) n++; return n; }
 const char *rmock_routine_name(int i) { return g_table[i].name; }
 int rmock_routine_nargs(int i) { return g_table[i].numArgs; }
@@ -176,6 +180,8 @@ void rmock_reset(void) { /* frees every object: call between tests, never while 
     g_protect = 0;
 }
 
+typedef SEXP (*fn2)(SEXP, SEXP);
+typedef SEXP (*fn3)(SEXP, SEXP, SEXP);
 typedef SEXP (*fn4)(SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*fn5)(SEXP, SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*fn6)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
@@ -195,7 +201,9 @@ int rmock_call(const char *name, int nargs, SEXP *a, SEXP *res) {
         g_protect = depth;
         return 1;
     }
-    if (nargs == 4) *res = ((fn4)d->fun)(a[0], a[1], a[2], a[3]);
+    if (nargs == 2) *res = ((fn2)d->fun)(a[0], a[1]);
+    else if (nargs == 3) *res = ((fn3)d->fun)(a[0], a[1], a[2]);
+    else if (nargs == 4) *res = ((fn4)d->fun)(a[0], a[1], a[2], a[3]);
     else if (nargs == 5) *res = ((fn5)d->fun)(a[0], a[1], a[2], a[3], a[4]);
     else if (nargs == 6) *res = ((fn6)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5]);
     else { g_jmp_armed = 0; return 2; }

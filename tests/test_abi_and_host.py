@@ -30,10 +30,27 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_code_object_is_gfx950_only():
+    """Every device code object in the library targets gfx950 and nothing else.  The objects are
+    compressed offload bundles (hipcc --offload-compress: 93.7 -> 40 MB, the library travels to the
+    GPU box on every run): header `CCOB`, version, method, total size, uncompressed size, hash,
+    then one zstd frame."""
+    import struct
+
+    import pyarrow as pa
     from ldsr_amd import _lib
     blob = open(_lib.SO_PATH, "rb").read()
-    assert b"amdgcn-amd-amdhsa--gfx950" in blob
-    assert b"gfx942" not in blob and b"gfx90a" not in blob
+    assert os.path.getsize(_lib.SO_PATH) < 64 << 20
+    triples, n, i = set(), 0, 0
+    while True:
+        i = blob.find(b"CCOB", i)
+        if i < 0:
+            break
+        total, usize, _ = struct.unpack_from("<QQQ", blob, i + 8)
+        raw = pa.Codec("zstd").decompress(blob[i + 32:i + total], usize).to_pybytes()
+        triples |= set(re.findall(rb"hip[a-z0-9]*-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", raw[:4096]))
+        n += 1
+        i += total
+    assert n >= 50 and triples == {b"gfx950"}, (n, triples)
 
 
 def test_argument_validation_without_gpu():

@@ -126,6 +126,39 @@ def test_registration_table_mirrors_the_reference(R):
                    "ldsrhip_Kalman_smoother": 5, "ldsrhip_propagate": 5, "ldsrhip_Mstep": 4}
 
 
+def test_loaded_as_ldsr_it_registers_the_reference_table(R, refdata):
+    """Deployment shape (ii): the same shim object built as ldsr.so answers R_init_ldsr with the
+    nine routines of src/RcppExports.cpp:132-143 -- names AND arities -- plus the two batched
+    entries; the five metric routines (host code) are called here through .Call."""
+    L = R.L
+    L.rmock_init_as_ldsr.restype = C.c_int
+    assert L.rmock_init_as_ldsr() == 1
+    try:
+        got = {L.rmock_routine_name(i).decode(): L.rmock_routine_nargs(i) for i in range(L.rmock_n_routines())}
+        reference = {"_ldsr_Kalman_smoother": 5, "_ldsr_Mstep": 4, "_ldsr_LDS_EM": 6, "_ldsr_propagate": 5,
+                     "_ldsr_NSE": 2, "_ldsr_nRMSE": 3, "_ldsr_corr": 2, "_ldsr_KGE": 2, "_ldsr_RE": 3}
+        assert {k: v for k, v in got.items() if k.startswith("_ldsr_")} == reference
+        assert {k: v for k, v in got.items() if not k.startswith("_ldsr_")} == {
+            "ldsrhip_LDS_EM_batch": 6, "ldsrhip_LDS_EM_grid": 6}
+        # the metric entries on fold 0 of the reference-held NPcv object
+        from ldsr_amd import cv
+        c = refdata["NPcv"]
+        z = np.asarray(c["Z"][0]) - 1
+        sim, obs = np.asarray(c["Ycv"])[0][z], np.asarray(c["target"])[z]
+        assert R.call("_ldsr_NSE", sim, obs)[0] == pytest.approx(c["metrics_dist"]["CE"][0], rel=1e-10)
+        assert R.call("_ldsr_KGE", sim, obs)[0] == pytest.approx(c["metrics_dist"]["KGE"][0], rel=1e-10)
+        assert R.call("_ldsr_corr", sim, obs)[0] == pytest.approx(np.corrcoef(sim, obs)[0, 1], rel=1e-12)
+        assert R.call("_ldsr_nRMSE", sim, obs, float(np.mean(c["target"])))[0] == pytest.approx(
+            c["metrics_dist"]["nRMSE"][0], rel=1e-10)
+        tr = np.delete(np.asarray(c["target"]), z)
+        assert R.call("_ldsr_RE", sim, obs, float(tr.mean()))[0] == pytest.approx(c["metrics_dist"]["RE"][0], rel=1e-10)
+        with pytest.raises(RuntimeError, match="one \\(positive\\) length"):
+            R.call("_ldsr_NSE", sim, obs[:5])
+        assert L.rmock_protect_depth() == 0
+    finally:
+        assert L.rmock_init() == 1            # back to the side-car table for the other tests
+
+
 def test_argument_errors_unwind_cleanly(R, p1case):
     c = p1case
     y = c["y"][None, :]
