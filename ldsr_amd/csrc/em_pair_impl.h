@@ -56,15 +56,73 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY_SBMASK     // what may still cross the per-step scheduling barriers (0x2 VALU | 0x4 SALU)
 #define LDSR_STEADY_SBMASK 0x6
 #endif
+#ifndef LDSR_W64_BU_RECOMPUTE   // one cell per wave: F2 re-forms B u_t from the image instead of keeping it
+#define LDSR_W64_BU_RECOMPUTE 1
+#endif
+#ifndef LDSR_W64_UNIFORM
+#define LDSR_W64_UNIFORM 1
+#endif
 #ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
 #define LDSR_STEADY_MIN_L 24
 #endif
+// steps of the transient block: two cells per wave L-1 (lane 0's chunk), one cell per wave the
+// first 64 / L chunks less one step (63 lanes hold a step each, the 64th is the template)
+__host__ __device__ constexpr int pair_steady_ntr(int L, int LPC) { return (LPC == 64 ? (64 / L) * L : L) - 1; }
 __host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
-    return LDSR_STEADY && LPC == 32 && L >= LDSR_STEADY_MIN_L &&
+    if (!LDSR_STEADY) return false;
+    if (LPC == 64)
+        return L <= 16 && pair_steady_ntr(L, LPC) >= LDSR_STEADY_MIN_L - 1 &&
+               (pair_image_doubles(L, PP, QQ, LPC) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
+    return LPC == 32 && L >= LDSR_STEADY_MIN_L &&
            (pair_image_doubles(L, PP, QQ, LPC) + 8 * pair_strip_doubles(L) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
 }
 
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
+
+// LPC = 64: ONE cell per wave (wide inputs: padded p or q = 8, chunks of <= 16 steps).  The
+// per-step values that must survive from the forward to the backward sweep then fit the
+// registers (3 x 16 doubles), so there is no strip; the image is the scan kernel's
+// (em_scan_impl.h: same layout, 64 virtual lanes).
+// Built with `make WAVE64=1` only.  Measured on BASELINE config 3 (T = 1000, p = 4, q = 8, 8192
+// cells x 100 iterations, same box): scan kernel 4.09 ms; this member 4.80 ms with its fallback,
+// 3.91 ms if every cell were steady -- 1820 VALU instructions per unit of which only 1041 are fp64
+// (scan kernel: 2192 / 1465): at 64 lanes x 16 steps the per-iteration fixed work (transient block
+// of 63 steps, two more scans, 21-value reduction, the (4,8) M-step) and the SGPR spill traffic of
+// a wave-uniform theta eat what the steady sweeps save.  Kept because it is parity-tested
+// (BASELINE config 3 whole, niter = 1000, tol = 1e-5) and a starting point, not selected by AUTO.
+__host__ __device__ constexpr bool pair_hreg(int LPC) { return LPC == 64; }
+
+// Cross-row step of the reverse scans.  After the four row-shift rounds lane l holds the
+// composite (P, G, H) of lanes l .. end of its 16-lane row; every lane then applies the composite
+// of all later rows of its cell (first lanes of those rows, read with v_readlane).  P is made
+// the full product too (callers whose terminal value is not zero need it).
+template <int LPC>
+__device__ __forceinline__ void rscan_cross(double &P, double &G, double &H, int lane) {
+    if constexpr (LPC == 32) {
+        const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16), P1 = readlane_d(P, 16);
+        const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48), P3 = readlane_d(P, 48);
+        const int row = lane >> 4;
+        const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
+        const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
+        const double Ps = row == 0 ? P1 : row == 2 ? P3 : 1.0;
+        G = fma(P, Gs, G);
+        H = fma(P * P, Hs, H);
+        P *= Ps;
+    } else if constexpr (LPC == 64) {
+        const double P3 = readlane_d(P, 48), G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
+        const double P2 = readlane_d(P, 32), G2 = readlane_d(G, 32), H2 = readlane_d(H, 32);
+        const double P1 = readlane_d(P, 16), G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
+        const double G23 = fma(P2, G3, G2), H23 = fma(P2 * P2, H3, H2), P23 = P2 * P3;      // rows 2, 3
+        const double G123 = fma(P1, G23, G1), H123 = fma(P1 * P1, H23, H1), P123 = P1 * P23;
+        const int row = lane >> 4;
+        const double Gs = row == 0 ? G123 : row == 1 ? G23 : row == 2 ? G3 : 0.0;
+        const double Hs = row == 0 ? H123 : row == 1 ? H23 : row == 2 ? H3 : 0.0;
+        const double Ps = row == 0 ? P123 : row == 1 ? P23 : row == 2 ? P3 : 1.0;
+        G = fma(P, Gs, G);
+        H = fma(P * P, Hs, H);
+        P *= Ps;
+    }
+}
 
 // Sums and likelihood terms of one E-step, as the sweeps leave them in every lane (reduced over the
 // cell's lanes afterwards by em_pair_body)
@@ -84,6 +142,8 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
                                                     const double *ys, double *hs, unsigned obsmask,
                                                     int lane, int nl, int rp, double x_t1, double v_t1) {
     constexpr int KP = scan_pairs(PP, QQ);
+    constexpr bool HREG = pair_hreg(LPC);        // h_t in registers (one cell per wave, L <= 16)
+    static_assert(!HREG || L <= 16, "one cell per wave: chunks of at most 16 steps");
     const int vl = lane & (LPC - 1);
     auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
     auto Yat = [&](int j) { return val(j, 0); };
@@ -107,7 +167,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
         for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
         return bu;
     };
-    double Jv[L], gv_[L];
+    double Jv[L], gv_[L], hv[HREG ? L : 1];
     double hlast = 0.0;      // h of the predicated step L-1
     double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
     int sneg = 0;
@@ -205,7 +265,8 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     M = pmul(M, pdpp<DPP_ROW_SHR(4), 0xF>(M));
     prenorm(M);
     M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
-    if constexpr (LPC == 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+    if constexpr (LPC >= 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
+    if constexpr (LPC == 64) { prenorm(M); M = pmul(M, pdpp<DPP_ROW_BCAST31, 0xC>(M)); }   // lane 31 -> rows 2, 3
     // exit state of this lane's chunk, then the entry state = exit state of the lane before
     // (lane 0 of each half: the cell's initial state)
     const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
@@ -267,7 +328,8 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
             h = fin ? Vu : h;
         }
         Jv[j] = J; gv_[j] = g;
-        if (j < L - 1) hs[j * 64] = h; else hlast = h;
+        if constexpr (HREG) hv[j] = h;
+        else { if (j < L - 1) hs[j * 64] = h; else hlast = h; }
         G = fma(Pi, g, G);
         H = fma(Pi * Pi, h, H);
         Pi *= J;
@@ -295,16 +357,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     }
     RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
 #undef RSCAN_ROUND
-    if constexpr (LPC == 32) {
-        // rows 0 and 2 apply the composite of the row after them (lanes 16 / 48)
-        const double G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
-        const double G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
-        const int row = lane >> 4;
-        const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
-        const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
-        G = fma(Pi, Gs, G);
-        H = fma(Pi * Pi, Hs, H);
-    }
+    rscan_cross<LPC>(Pi, G, H, lane);      // later rows of the cell
     // (G, H) = (Xs, Vs) at the first step of the chunk; the value just after this lane's
     // chunk is the next lane's, and the zero terminal value for the half's last lane
     double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
@@ -319,7 +372,9 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     auto b2a = [&](int j) {
         const bool o = DENSE || ((obsmask >> j) & 1u);
         const double J = Jv[j];
-        const double h = (j < L - 1) ? hs[j * 64] : hlast;
+        double h;
+        if constexpr (HREG) h = hv[j];
+        else h = (j < L - 1) ? hs[j * 64] : hlast;
         aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
         const double Xs = fma(J, Xn, gv_[j]);       // :101
         const double Vs = fma(J * J, Vn, h);        // :102
@@ -372,9 +427,11 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
 // inlined next to the steady sweeps their 244 registers made the allocator spill values that live
 // across the whole EM loop on the steady path too.
 template <int PP, int QQ, int L, int LPC, bool DENSE>
-__device__ __attribute__((noinline)) void pair_generic_sweeps_call(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> &th,
+__device__ __attribute__((noinline)) void pair_generic_sweeps_call(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> th,
                                                                    const double *ys, double *hs, unsigned obsmask,
                                                                    int lane, int nl, int rp, double x_t1, double v_t1) {
+    // (theta BY VALUE: handed over by reference, the caller's theta lived on its stack and was
+    // re-read from scratch at the top of every EM iteration, steady or not)
     PairSweepOut<PP, QQ> t;
     pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(t, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
     o = t;
@@ -385,9 +442,11 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                                              const double *lu, const double *tri, int s, int c0, int nc, int lane,
                                              int wave) {
     static_assert(!(LEAD && DENSE), "a lead of missing steps and a fully observed series exclude each other");
-    static_assert(!STEADY || (DENSE && LPC == 32), "the steady sweeps: fully observed series, two cells per wave");
+    static_assert(!STEADY || (DENSE && LPC >= 32), "the steady sweeps: fully observed series, one or two cells per wave");
+    static_assert(!(LEAD && LPC == 64), "no closed-form lead for one cell per wave");
     constexpr int KP = scan_pairs(PP, QQ);
-    static_assert(LPC == 32 || LPC == 16, "two or four cells per wave");
+    static_assert(LPC == 64 || LPC == 32 || LPC == 16, "one, two or four cells per wave");
+    constexpr bool HREG = pair_hreg(LPC);
     constexpr int CPW = 64 / LPC;                         // cells per wave
     // `half` = which cell of the wave this lane works for (the name dates from LPC = 32)
     const int half = lane / LPC, vl = lane & (LPC - 1), hbase = lane & ~(LPC - 1);
@@ -397,8 +456,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #pragma unroll
         for (int i = 0; i < 2 * KP; i++) w[i] = val(j, i);
     };
-    constexpr int PF = LDSR_STEADY_PF;       // steady sweeps: steps the image is read ahead
-    constexpr int PF2 = LDSR_STEADY_PF2;     // ... and the strip
+    // steady sweeps: steps the image is read ahead (a step is KP 16-byte pairs: wide inputs get a
+    // shorter ring) and the strip
+    constexpr int PF = KP <= 2 ? LDSR_STEADY_PF : (KP <= 4 ? 2 : 1);
+    constexpr int PF2 = LDSR_STEADY_PF2;
     // LEAD: the first `lead` steps of every series of the launch are unobserved and are handled in
     // closed form (below); the sweeps work on the tail [lead, T) only, all indices tail relative
     const int lead = LEAD ? prm.lead : 0;
@@ -434,10 +495,24 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     Theta<PP, QQ> th;
     load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
     white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
+    // one cell per wave: theta is wave-uniform by construction; say so to the compiler (SGPR residency)
+    auto make_uniform = [](Theta<PP, QQ> &t) {
+        t.A = uniform_d(t.A); t.C = uniform_d(t.C); t.Q = uniform_d(t.Q);
+        t.R = uniform_d(t.R); t.mu1 = uniform_d(t.mu1); t.V1 = uniform_d(t.V1);
+#pragma unroll
+        for (int k_ = 0; k_ < PP; k_++) t.B[k_] = uniform_d(t.B[k_]);
+#pragma unroll
+        for (int k_ = 0; k_ < QQ; k_++) t.D[k_] = uniform_d(t.D[k_]);
+    };
+    if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
 
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
     double gv_[STEADY ? L : 1];   // steady sweeps: e_t, then g_t of this lane's steps
+    // ... and B u_t where there is no strip (one cell per wave) -- unless F2 re-forms it from the
+    // image (LDSR_W64_BU_RECOMPUTE: p products and ~p/2 LDS reads per step for 2 L registers)
+    constexpr bool BUREG = STEADY && HREG && !LDSR_W64_BU_RECOMPUTE;
+    double buv[BUREG ? L : 1];
     int wit = 0;             // wave-uniform iteration count (interrupt poll)
 
     while (__any(alive)) {
@@ -551,12 +626,17 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
         double addPall = 0.0, addTx1x = 0.0;    // STEADY: closed-form variance sums of the steady region
         int sneg = 0;
-        double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0, aSxx = 0.0;
+        // (zeroed where a branch starts to accumulate, not here: as values defined at the top of the
+        // iteration they held 2 (5 + q + 2p) registers through the forward sweeps -- 42 at p = 4, q = 8)
+        double aSyx, aTx1x, aPall, aSxx = 0.0;
         double aSxv[QQ], aTx1u[PP], aTux[PP];
+        auto zero_sums = [&]() {
+            aSyx = 0.0; aTx1x = 0.0; aPall = 0.0;
 #pragma unroll
-        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+            for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
 #pragma unroll
-        for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+            for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+        };
 
         // ------------------------------------------------ STEADY: transient block and verdict
         // With every y_t observed the variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t:
@@ -574,7 +654,11 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         // sweeps take 50, no h_t strip, the variance sums in closed form.  Cells that fail (slow
         // Riccati convergence: A near 1 with a small gain, mostly in the first EM iterations) take
         // the generic sweeps for this iteration.
-        constexpr int NTR = L - 1;
+        // One cell per wave (LPC = 64): the 63 other lanes make the transient block K0 = 64 / L chunks
+        // long; lanes 0 .. K0-2 then have no steady step, lane K0-1 its predicated step only.
+        constexpr int K0 = LPC == 64 ? 64 / L : 1;
+        constexpr int NTR = K0 * L - 1;
+        static_assert(!STEADY || NTR < LPC, "the last lane of the cell is the template, not a transient step");
         bool st = false;
 #ifdef LDSR_STEADY_DEBUG
         double dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -618,6 +702,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 VSCAN_SHR(8)
                 VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
                             (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
+                if constexpr (LPC == 64)
+                    VSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, p00)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p01)),
+                                (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p10)), (dppd<DPP_ROW_BCAST31, 0xC>(1.0, p11)))
 #undef VSCAN_SHR
 #undef VSCAN_ROUND
                 double n_e = fma(p00, th.V1, p01), d_e = fma(p10, th.V1, p11);
@@ -647,6 +734,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 MSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
                 MSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
                 MSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+                if constexpr (LPC == 64) MSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
 #undef MSCAN_ROUND
                 Xp = fma(al, th.mu1, bl);
                 Xp = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xp);
@@ -666,8 +754,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             const bool conv = fabs(Vp1 - Vp) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && J * J < 0.8;
             const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
             const unsigned long long cvm = __ballot(conv);
-            const unsigned hm = (unsigned)(okm >> hbase), hc = (unsigned)(cvm >> hbase);
-            st = alive && hm == 0xFFFFFFFFu && (hc >> 31) != 0u;
+            constexpr unsigned long long CELL = LPC == 64 ? ~0ull : ((1ull << (LPC & 63)) - 1ull);
+            const unsigned long long hm = (okm >> hbase) & CELL, hc = (cvm >> hbase) & CELL;
+            // (rp >= K0: the first K0 lanes own L steps each, so the block ends on a chunk boundary)
+            st = alive && hm == CELL && ((hc >> (LPC - 1)) & 1ull) != 0ull && rp >= K0 && nl > K0;
             const int src = hbase | (LPC - 1);
             cK = shfl_d(K, src); cJ = shfl_d(J, src); cr = shfl_d(r0, src); cVu = shfl_d(Vu, src);
             ch = shfl_d(trH, src); clg = shfl_d(lg, src); X_tr = shfl_d(Xp, src);
@@ -676,10 +766,11 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
         }
 
-        if (STEADY && __builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
+        if constexpr (STEADY) if (__builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
             // ============================================ steady sweeps over t = NTR .. T-1
-            // Lane 0 keeps only its predicated step L-1 (= step NTR); lanes 1.. their whole chunks.
-            const bool body = act && vl > 0;
+            // Lane K0-1 keeps only its predicated step L-1 (= step NTR); lanes K0.. their whole chunks.
+            const bool body = act && vl >= K0;
+            const bool tail_s = tail && vl >= K0 - 1;
             const double aK = A * cK, a = fma(-aK, C, A);           // Xp_{t+1} = a Xp_t + (A K e_t + B u_t)
             // a^(L-1), J^(L-1): multipliers of a whole chunk
             double aL = 1.0, JL = 1.0;
@@ -709,12 +800,14 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #pragma unroll
                 for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], w[1 + p_], bu);
                 gv_[j] = e;
-                if (j < L - 1) hs[j * 64] = bu; else buLast = bu;     // B u_t waits for F2 in the wave's LDS strip
+                if constexpr (BUREG) buv[j] = bu;                     // (one cell per wave: registers)
+                else if constexpr (!HREG) { if (j < L - 1) hs[j * 64] = bu; else buLast = bu; }   // B u_t waits for F2 in the wave's LDS strip
                 bl = fma(a, bl, fma(aK, e, bu));
             };
             {
+                constexpr bool PRET = KP <= 4;       // the predicated step's values read ahead too (narrow inputs)
                 double Wt[2 * KP], W[PF][2 * KP];
-                ldw(L - 1, Wt);
+                if constexpr (PRET) ldw(L - 1, Wt);
 #pragma unroll
                 for (int d = 0; d < PF; d++) ldw(d, W[d]);
                 __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
@@ -727,7 +820,11 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     }
                     al = aL;
                 }
-                if (tail) { f1s(L - 1, Wt); al *= a; }
+                if (tail_s) {
+                    if constexpr (!PRET) ldw(L - 1, Wt);
+                    f1s(L - 1, Wt);
+                    al *= a;
+                }
             }
             // ---- inclusive scan over the cell's lanes, then the entry state of this lane
 #define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
@@ -736,6 +833,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             SSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
             SSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
             SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+            if constexpr (LPC == 64) SSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
 #undef SSCAN_ROUND
             double Xp = fma(al, X_tr, bl);                           // after this lane's steps
             Xp = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xp);
@@ -753,38 +851,56 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 const double Xp1 = fma(A, Xu, bu);                 // :74
                 double g = fma(-cJ, Xp1, Xu);
                 if (j >= L - 2) {
-                    const bool fin = (vl == lastLane) && (j == (tail ? L - 1 : L - 2));
+                    const bool fin = (vl == lastLane) && (j == (tail_s ? L - 1 : L - 2));
                     g = fin ? Xu : g;                              // step T-1: Xs = Xu
                 }
                 gv_[j] = g;
                 Xp = Xp1;
             };
-            if (body) {
-                double U[PF2];
+            if constexpr (HREG) {
+                auto bu_of = [&](int j) {
+                    if constexpr (BUREG) return buv[j];
+                    double bu = 0.0;
 #pragma unroll
-                for (int d = 0; d < PF2; d++) U[d] = hs[d * 64];
-                __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], val(j, 1 + p_), bu);
+                    return bu;
+                };
+                if (body) {
 #pragma unroll
-                for (int j = 0; j < L - 1; j++) {
-                    f2s(j, U[j % PF2]);
-                    if (j + PF2 < L - 1) U[j % PF2] = hs[(j + PF2) * 64];
-                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    for (int j = 0; j < L - 1; j++) f2s(j, bu_of(j));
                 }
-            }
-            if (tail) f2s(L - 1, buLast);
-            // B2's first reads of the image are issued here, ahead of the reverse scan
-            double Vt[2 * KP], V[PF][2 * KP];
-            ldw(L - 1, Vt);
+                if (tail_s) f2s(L - 1, bu_of(L - 1));
+            } else {
+                if (body) {
+                    double U[PF2];
 #pragma unroll
-            for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+                    for (int d = 0; d < PF2; d++) U[d] = hs[d * 64];
+                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+#pragma unroll
+                    for (int j = 0; j < L - 1; j++) {
+                        f2s(j, U[j % PF2]);
+                        if (j + PF2 < L - 1) U[j % PF2] = hs[(j + PF2) * 64];
+                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    }
+                }
+                if (tail_s) f2s(L - 1, buLast);
+            }
+            // B2's first reads of the image are issued here, ahead of the reverse scan
+            constexpr bool PRET2 = KP <= 4;
+            double Vt[2 * KP], V[PF][2 * KP];
+            if constexpr (PRET2) {
+                ldw(L - 1, Vt);
+#pragma unroll
+                for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+            }
             __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
             tLv = fma(Xu, Xu, cVu);
-            const int nst = (body ? L - 1 : 0) + (tail ? 1 : 0);    // steady steps of this lane
+            const int nst = (body ? L - 1 : 0) + (tail_s ? 1 : 0);    // steady steps of this lane
             likq = fma(cr, lq, trLq);
             lsp = fma((double)nst, clg, trLg);
             // ---- reverse composite of the chunk (constant multiplier J), reverse scan
             double Pi = 1.0, G = 0.0;
-            if (tail) { G = gv_[L - 1]; Pi = cJ; }
+            if (tail_s) { G = gv_[L - 1]; Pi = cJ; }
             if (body) {
 #pragma unroll
                 for (int j = L - 2; j >= 0; j--) G = fma(cJ, G, gv_[j]);
@@ -794,18 +910,17 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
 #undef RSCAN_ROUND
             {
-                const double G1 = readlane_d(G, 16), G3 = readlane_d(G, 48);
-                const int row = lane >> 4;
-                const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
-                G = fma(Pi, Gs, G);
+                double Hdummy = 0.0;
+                rscan_cross<LPC>(Pi, G, Hdummy, lane);
             }
             double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
             if (vl == LPC - 1) Xn = 0.0;
-            const double XsS = shfl_d(G, hbase);                    // Xs at t = NTR (lane 0's step L-1)
+            const double XsS = shfl_d(G, hbase | (K0 - 1));         // Xs at t = NTR (step L-1 of lane K0-1)
 #ifdef LDSR_STEADY_DEBUG
             dbg[5] = Xn; dbg[8] = G;
 #endif
             // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
+            zero_sums();
             auto b2s = [&](int j, const double (&w)[2 * KP]) {
                 const double Xs = fma(cJ, Xn, gv_[j]);             // :101
                 aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
@@ -821,7 +936,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, w[1 + PP + q_], aSxv[q_]);   // :159
                 Xn = Xs;
             };
-            if (tail) b2s(L - 1, Vt);
+            if constexpr (!PRET2) {
+                if (tail_s) ldw(L - 1, Vt);
+#pragma unroll
+                for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+            }
+            if (tail_s) b2s(L - 1, Vt);
             if (body) {
 #pragma unroll
                 for (int j = L - 2; j >= 0; j--) {
@@ -846,6 +966,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             // ---- transient block backwards: composite of steps vl .. NTR-1 applied to (XsS, VsS)
             {
                 const bool trl = vl < NTR;
+                // (the block's y, u, v are read from LDS AGAIN: through a lane index the compiler cannot
+                // match with the forward block's, or it keeps all 1 + p + q values alive -- in scratch,
+                // for wide inputs -- across the steady sweeps)
+                int vl2 = vl;
+                asm volatile("" : "+v"(vl2));
+                auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl2) * 2 + (i & 1)]; };
                 double Pt = trl ? trJ : 1.0, Gt = trl ? trG : 0.0, Ht = trl ? trH : 0.0;
 #define RSCAN_ROUND(n)                                                     \
                 {                                                          \
@@ -858,17 +984,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 }
                 RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
 #undef RSCAN_ROUND
-                {
-                    const double G1 = readlane_d(Gt, 16), H1 = readlane_d(Ht, 16), P1 = readlane_d(Pt, 16);
-                    const double G3 = readlane_d(Gt, 48), H3 = readlane_d(Ht, 48), P3 = readlane_d(Pt, 48);
-                    const int row = lane >> 4;
-                    const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
-                    const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
-                    const double Ps = row == 0 ? P1 : row == 2 ? P3 : 1.0;
-                    Gt = fma(Pt, Gs, Gt);
-                    Ht = fma(Pt * Pt, Hs, Ht);
-                    Pt *= Ps;                    // (the terminal value at t = NTR is not zero here)
-                }
+                rscan_cross<LPC>(Pt, Gt, Ht, lane);     // (full products: the terminal value at t = NTR is not zero)
                 const double XsT = fma(Pt, XsS, Gt), VsT = fma(Pt * Pt, VsS, Ht);   // at step vl (vl >= NTR: at NTR)
                 const double XsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, XsT);
                 const double VsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, VsT);
@@ -890,7 +1006,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 dbg[6] = XsT; dbg[7] = VsT;
 #endif
             }
-        } else if (!STEADY || alive) {
+        }
+        if (!st && STEADY && !alive) zero_sums();     // (an idle half: nothing ran)
+        if (!st && (!STEADY || alive)) {
 #ifndef LDSR_STEADY_ONLY_EXPERIMENT   // (timing experiment: no fallback at all -- results wrong for slow cells)
             PairSweepOut<PP, QQ> o;
             if constexpr (STEADY) pair_generic_sweeps_call<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
@@ -954,7 +1072,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             }
             const double term0 = fma(S.X0, S.X0, S.V0);
             const unsigned long long negm = __ballot(sneg < 0);
-            const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
+            const bool neg = ((negm >> hbase) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63)) - 1ull))) != 0;   // log of a negative Sigma
             S.Syx = red[0]; S.Tx1x = red[1];
             S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
@@ -1012,6 +1130,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                         cell = c0 + kn;
                         load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
                         white_in(th, (SeriesConstK)sc);
+                        if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
                         it = 0;
                         lik = NAN; lik1 = NAN; lik2 = NAN;
                     }
@@ -1020,6 +1139,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         } else {
             mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
         }
+        if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
     }
 }
 
@@ -1038,7 +1158,8 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
     // LEAD: the (whitened) u_t of the all-missing first prm.lead steps, [step of the lane][lane][PP],
     // behind the strips
-    double *lu = smem + IMG + (long)(blockDim.x >> 6) * pair_strip_doubles(L);
+    constexpr long STRIP = pair_hreg(LPC) ? 0 : pair_strip_doubles(L);     // (one cell per wave: no strips)
+    double *lu = smem + IMG + (long)(blockDim.x >> 6) * STRIP;
     if constexpr (LEAD) {
         const int n3 = ((prm.lead + LPC - 1) / LPC) * LPC * PP;
         const double *g3 = prm.img3 + (long)s * prm.img3_stride;
@@ -1049,9 +1170,10 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     const double *tri = lu;
     if constexpr (STEADY) {
         constexpr int KP = scan_pairs(PP, QQ);
+        constexpr int NTR = pair_steady_ntr(L, LPC);
         for (int i = threadIdx.x; i < KP * LPC * 2; i += blockDim.x) {
-            const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;
-            lu[i] = l < L - 1 ? gimg[((l * KP + m) * LPC) * 2 + c] : 0.0;
+            const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;      // step l = step l % L of lane l / L
+            lu[i] = l < NTR ? gimg[(((l % L) * KP + m) * LPC + l / L) * 2 + c] : 0.0;
         }
     }
     __syncthreads();
@@ -1072,7 +1194,7 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
         return;
     }
     if (!QUEUE && (64 / LPC) * wave >= nc) return;    // whole wave leaves; no barrier follows
-    double *hs = smem + IMG + (long)wave * pair_strip_doubles(L) + lane;
+    double *hs = smem + IMG + (long)wave * STRIP + lane;
     const bool dense = sc->n_obs == prm.T;
     if constexpr (LEAD) {
         em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);

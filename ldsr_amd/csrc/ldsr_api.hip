@@ -703,12 +703,22 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
     if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
-    const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;      // several cells per wave
+    // Wide inputs (padded p or q = 8), every series fully observed: the scan kernel's plan and image,
+    // the pair family's body with its steady-state sweeps, ONE cell per wave (LDSR_WAVE64=0: off)
+    static const bool wave64_on = [] { const char *e = getenv("LDSR_WAVE64"); return !(e && atoi(e) == 0); }();
+    const bool wave64 = algo == LDSR_ALGO_SCAN && was_auto && dense_hint == 1 && wave64_on && pair_enabled() &&
+                        em_pair_supported(T, PP, QQ, 64);
+    if (wave64) lpc = 64;
+    const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD || wave64;      // the pair family's body
     if (algo_used) *algo_used = algo;
-    const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
+    const int cpb = wave64 ? em_pair_cells_per_block(T, PP, QQ, 64)
+                           : cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
-    if (cpw) {       // the image of the member that runs (the room is for the largest)
+    if (wave64) {    // (reads the scan kernel's image: same layout)
+        L.img2_stride = 0;
+        L.img3_stride = 0;
+    } else if (cpw) {       // the image of the member that runs (the room is for the largest)
         long sz = 0;
         em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz);
         L.img2_NL = lpc;
@@ -771,6 +781,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.img_stride = L.img_stride;
     prm.img2 = L.img2_stride ? (const double *)(ws + L.img2) : nullptr;
     prm.img2_stride = L.img2_stride;
+    if (wave64) { prm.img2 = prm.img; prm.img2_stride = L.img_stride; }
     prm.lead = cpw ? lead : 0;
     prm.img3 = (cpw && lead > 0) ? (const double *)(ws + L.img3) : nullptr;
     prm.img3_stride = L.img3_stride;
