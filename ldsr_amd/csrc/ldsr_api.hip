@@ -519,6 +519,11 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     tail = (tail + 15) / 16 * 16;
     static const int max_tail = [] { const char *e = getenv("LDSR_LEAD_MAX_TAIL"); return e ? atoi(e) : 512; }();
     if (tail > max_tail || tail > 512 || T - tail < 128) return 0;
+    // p = 3, 4 have the two-cells-per-wave LEAD form only (7 + 4 p lead sums per step): on short
+    // series the four-cells-per-wave kernel over all T steps is quicker (tools/auto_regret.py, same
+    // box: T = 260 (4,4) 20 000 cells 1.86 ms against 1.29, to convergence 11.4 against 7.0; the Nakhon
+    // Phanom shape, T = 813 with a lead of 733 steps, keeps it: 3.29 -> 2.50 ms)
+    if (PP > 2 && T - tail < 512) return 0;
     // the lead's u_t live in LDS behind the tail's image and the eight strips
     auto fits = [&](int lp) {
         int Lc = 0;
@@ -570,7 +575,7 @@ static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, ch
     } else if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
         // AUTO (a launch that fills the device assumed): four cells per wave where they fit, else two
         int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
-        if (was_auto && !masked_conv && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+        if (was_auto && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
         if (!em_pair_supported(T, PP, QQ, lpc)) return -1;
         if (buf && len) em_pair_kernel_name(T, PP, QQ, lpc, tol > 0.0, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
@@ -690,7 +695,10 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
         // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
         if (was_auto && algo == LDSR_ALGO_PAIR) {
-            if (!masked_conv && fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+            // (masked series with early stopping reach this point only as short series: there four
+            // cells per wave win once the launch is large -- tools/auto_regret.py, 20 000 cells:
+            // T = 260 (4,4) 9.5 -> 7.0 ms, T = 150 (1,2) 2.96 -> 2.74; at 2000 cells two per wave stay ahead)
+            if (fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(T, 32)) lpc = 32;
             else algo = em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
         }
