@@ -444,6 +444,9 @@ def main():
                 "algorithmic_flops_per_unit": fpu, "units_per_launch": units_rank,
                 "hbm_logical_bytes_per_unit": bpu, "hbm_logical_gbs": logical_gbs,
                 "hbm_logical_frac": logical_gbs / HBM_PEAK_GBS, "hbm_peak_gbs": HBM_PEAK_GBS,
+                "flops_are": "reference-equivalent: what src/EM.cpp spends on these units, (6p+6q+50) T "
+                             "each; kernels with a closed-form lead or steady-state sweeps execute "
+                             "fewer -- fp64_executed_frac is what the SQ counters saw",
                 "note": "fp64 VALU issue is the binding resource; hbm_logical_* is BASELINE.json's "
                         "nominal byte figure (not traffic: the series is served from LDS, the "
                         "filtered states never leave registers) and may exceed 1; traffic / "
