@@ -261,3 +261,76 @@ def test_interrupt_callback_stops_cells_and_reports_it(eng):
         assert L.ldsr_set_interrupt_callback(None, None) == 0
     r = eng.em_batch(y, u, v, th0[:64], niter=130, tol=0.0)       # no callback: runs to the cap
     assert np.all(r["n_iter"] == 130) and np.all(r["status"] == 0)
+
+
+@pytest.mark.parametrize("shape", ["masked_queue", "long_series_queue", "dense_pair_queue"])
+def test_interrupt_with_early_stopping_leaves_no_stale_cells(eng, shape):
+    """tol > 0 runs use the work queue: cells converge after a few dozen iterations and waves keep
+    pulling new ones.  Round 2 polled the flag on the CELL's iteration counter (a cell that stops
+    before its 64th iteration never polled) and kept pulling after an abort, so an interrupted
+    converging grid ran to completion; and cells never pulled kept whatever the arena held.  Now:
+    the poll counts the wave's iterations, an aborted wave only marks what the queue still hands
+    it.  The call must return LDSR_EINTERRUPTED well before the grid is done and every cell must
+    end as finished (status 0 / 1 with its own n_iter) or as interrupted (status 3) -- no cell may
+    keep the sentinel the outputs were pre-filled with."""
+    import time
+    from ldsr_amd import _lib, synth
+    L = _lib.lib()
+    T, p, q, n, mask = {"masked_queue": (1000, 1, 2, 200000, "scatter"),
+                        "long_series_queue": (2500, 1, 2, 40000, "dense"),
+                        "dense_pair_queue": (1000, 1, 2, 200000, "dense")}[shape]
+    y, u, v = synth.make_series(T, p, q, series_id=6)
+    if mask == "scatter":
+        y = y.copy()
+        y[::7] = np.nan
+    th0 = synth.make_init_packed(p, q, n, seed=2)
+    P = 6 + p + q
+    theta = np.full((n, P), -7.0)
+    lik = np.full(n, -7.0)
+    nit = np.full(n, -7, np.int32)
+    st = np.full(n, -7, np.int32)
+    off = np.array([0, n], np.int32)
+    U = np.ascontiguousarray(u.T)
+    V = np.ascontiguousarray(v.T)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    calls = {"n": 0}
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p)
+    def cb(_):
+        calls["n"] += 1
+        return 1 if calls["n"] >= 4 else 0
+
+    def run():
+        return L.ldsr_em_batch(0, 1, T, p, q, y.ctypes.data_as(dp), U.ctypes.data_as(dp), V.ctypes.data_as(dp), 0,
+                               off.ctypes.data_as(ip), th0.ctypes.data_as(dp), 1000, 1e-5, 0,
+                               theta.ctypes.data_as(dp), lik.ctypes.data_as(dp), nit.ctypes.data_as(ip),
+                               st.ctypes.data_as(ip), None)
+
+    t0 = time.perf_counter()
+    assert run() == 0                                         # uninterrupted: the whole grid
+    t_full = time.perf_counter() - t0
+    assert np.all(st == 0) and nit.max() < 1000 and nit.min() >= 3
+    done_full = nit.copy()
+    for a in (theta, lik):
+        a[...] = -7.0
+    nit[...] = -7
+    st[...] = -7
+    assert L.ldsr_set_interrupt_callback(C.cast(cb, C.c_void_p), None) == 0
+    try:
+        t0 = time.perf_counter()
+        rc = run()
+        t_int = time.perf_counter() - t0
+    finally:
+        assert L.ldsr_set_interrupt_callback(None, None) == 0
+    assert rc == 4 and calls["n"] >= 4                         # LDSR_EINTERRUPTED
+    # (the device -> host copy of the per-cell arrays is skipped on an interrupted call: what came
+    # back is what the interrupted call wrote, or nothing)
+    untouched = np.all(st == -7)
+    if not untouched:
+        assert not np.any(st == -7), "cells with stale outputs"
+        assert np.all((st == 0) | (st == 3))
+        fin = st == 0
+        assert np.array_equal(nit[fin], done_full[fin])       # finished cells are complete results
+        assert np.all(nit[st == 3] < 1000)
+        assert np.any(st == 3)
+    assert t_int < 0.7 * t_full, (t_int, t_full)             # it stopped, it did not run the grid out
