@@ -422,6 +422,21 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
 #pragma unroll
     for (int p_ = 0; p_ < PP; p_++) { o.aTx1u[p_] = aTx1u[p_]; o.aTux[p_] = aTux[p_]; }
 }
+// The same as a real call: in the STEADY form of em_pair_body the generic sweeps are the rare
+// fallback (cells whose Riccati recursion has not converged within the transient block), and
+// inlined next to the steady sweeps their 244 registers made the allocator spill values that live
+// across the whole EM loop on the steady path too.
+template <int PP, int QQ, int L, int LPC, bool DENSE>
+__device__ __attribute__((noinline)) void pair_generic_sweeps_call(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> th,
+                                                                   const double *ys, double *hs, unsigned obsmask,
+                                                                   int lane, int nl, int rp, double x_t1, double v_t1) {
+    // (theta BY VALUE: handed over by reference, the caller's theta lived on its stack and was
+    // re-read from scratch at the top of every EM iteration, steady or not)
+    PairSweepOut<PP, QQ> t;
+    pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(t, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+    o = t;
+}
+
 template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD, bool STEADY = false>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
                                              const double *lu, const double *tri, int s, int c0, int nc, int lane,
@@ -651,10 +666,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         double cK = 0.0, cJ = 0.0, cr = 0.0, cVu = 0.0, ch = 0.0, clg = 0.0, X_tr = 0.0;
         double trJ = 0.0, trG = 0.0, trH = 0.0, trLq = 0.0, trLg = 0.0;
         auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl) * 2 + (i & 1)]; };
-        // The pieces of an iteration are lambdas (forced inline): the common case runs transient block ->
-        // steady sweeps -> finish; a wave with a cell that failed the verdict runs them in another
-        // order in a cold block of its own (below).
-        auto transient_block = [&]() __attribute__((always_inline)) {
+        if constexpr (STEADY) {
             const bool trl = vl < NTR;
             double e_t = tval(0), bu_t = 0.0;                       // (tri is zero for vl >= NTR)
 #pragma unroll
@@ -752,9 +764,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #ifdef LDSR_STEADY_DEBUG
             dbg[0] = Xp; dbg[1] = Vp; dbg[2] = trG; dbg[3] = trJ; dbg[11] = st ? 1.0 : 0.0;
 #endif
-        };
+        }
 
-        auto steady_sweeps = [&]() __attribute__((always_inline)) {                  // (for the lanes of cells with st)
+        if constexpr (STEADY) if (__builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
             // ============================================ steady sweeps over t = NTR .. T-1
             // Lane K0-1 keeps only its predicated step L-1 (= step NTR); lanes K0.. their whole chunks.
             const bool body = act && vl >= K0;
@@ -994,11 +1006,13 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 dbg[6] = XsT; dbg[7] = VsT;
 #endif
             }
-        };
-        auto generic_sweeps = [&]() __attribute__((always_inline)) {
+        }
+        if (!st && STEADY && !alive) zero_sums();     // (an idle half: nothing ran)
+        if (!st && (!STEADY || alive)) {
 #ifndef LDSR_STEADY_ONLY_EXPERIMENT   // (timing experiment: no fallback at all -- results wrong for slow cells)
             PairSweepOut<PP, QQ> o;
-            pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+            if constexpr (STEADY) pair_generic_sweeps_call<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+            else pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
             aSyx = o.aSyx; aTx1x = o.aTx1x; aPall = o.aPall; aSxx = o.aSxx;
             likq = o.likq; lsp = o.lsp; tLv = o.tLv; X0v = o.X0v; V0v = o.V0v; sneg = o.sneg;
 #pragma unroll
@@ -1006,10 +1020,9 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #pragma unroll
             for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = o.aTx1u[p_]; aTux[p_] = o.aTux[p_]; }
 #endif
-        };
+        }
 
         // ------------------------------------------------ one reduction per half, M-step, stop rule
-        auto finish_iteration = [&]() __attribute__((always_inline)) {
         Sums<PP, QQ> S;
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);
@@ -1127,39 +1140,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
         }
         if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
-        };
-
-        // ------------------------------------------------ the iteration
-        if constexpr (STEADY) {
-            if (!prm.steady_off) transient_block();
-            // does a cell of this wave need the generic sweeps?  (wave-uniform: s_cbranch)
-            const bool mixed = __any(alive && !st) != 0;
-            if (__builtin_expect(!mixed, 1)) {
-                if (st) steady_sweeps();
-                else zero_sums();                     // (an idle half: nothing ran)
-                finish_iteration();
-            } else {
-                // Rare (1.2 % of the cell-iterations of config 2, 2.4 % of the wave-iterations) and
-                // therefore kept OUT of the common path above: the generic sweeps need 244 registers,
-                // and whatever shares a region with them pays in spill code -- inlined behind the
-                // steady sweeps they cost the steady path 20 %, as a real call (callee-saved
-                // registers: ~300 scratch accesses per call) they ran at less than half the speed
-                // of the plain generic kernel, and a slow cell keeps its wave here for tens of
-                // iterations.  So: the generic sweeps FIRST, with nothing of the steady path alive,
-                // then the transient block AGAIN for a partner that passed and its steady sweeps.
-                const bool was_st = st;
-                if (alive && !st) generic_sweeps();
-                if (__any(was_st)) {
-                    transient_block();
-                    if (st) steady_sweeps();
-                }
-                if (!alive) zero_sums();
-                finish_iteration();
-            }
-        } else {
-            generic_sweeps();
-            finish_iteration();
-        }
     }
 }
 

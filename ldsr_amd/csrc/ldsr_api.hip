@@ -791,10 +791,6 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.img2_stride = L.img2_stride;
     if (wave64) { prm.img2 = prm.img; prm.img2_stride = L.img_stride; }
     prm.lead = cpw ? lead : 0;
-    {
-        static const int so_env = [] { const char *e = getenv("LDSR_STEADY_OFF"); return e ? atoi(e) : -1; }();
-        prm.steady_off = so_env > 0 ? 1 : 0;
-    }
     prm.img3 = (cpw && lead > 0) ? (const double *)(ws + L.img3) : nullptr;
     prm.img3_stride = L.img3_stride;
     prm.fitX = prm.fitY = prm.fitV = prm.fitJ = prm.pen = nullptr;

@@ -302,7 +302,6 @@ struct EmParams {
     long img_stride;         // doubles per series image
     const double *img2;      // pair kernel (em_pair_impl.h): [n_series] images in its 32-lane layout, or null
     long img2_stride;
-    int steady_off;          // pair kernel: 1 = fully observed series take the generic sweeps only (em_pair_impl.h STEADY)
     int lead;                // pair kernel: all-missing first steps of every series handled in closed form (0 = none)
     const double *img3;      // ... and their (whitened) u_t, [n_series][step of the lane][lane][PP]
     long img3_stride;
