@@ -97,24 +97,7 @@ __host__ __device__ constexpr int red_slot(int v, int n, int width) {
     return v;
 }
 template <int N, int D>
-__device__ __forceinline__ void red_rounds(double *x, int lane) {
-    if constexpr (D >= 1) {
-        constexpr int NK = (N + 1) / 2, NF = N - NK;
-        const bool up = (lane & D) != 0;
-        double snd[NK], kp[NK];
-#pragma unroll
-        for (int i = 0; i < NK; i++) {
-            const double hi = (i < NF) ? x[NK + i] : 0.0;   // (an odd count leaves one padded slot)
-            snd[i] = up ? x[i] : hi;
-            kp[i] = up ? hi : x[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NK; i++) snd[i] = __shfl_xor(snd[i], D, 64);
-#pragma unroll
-        for (int i = 0; i < NK; i++) x[i] = kp[i] + snd[i];
-        red_rounds<NK, D / 2>(x, lane);
-    }
-}
+__device__ __forceinline__ void red_rounds(double *x, int lane);   // (below, after the DPP helpers)
 // Butterfly all-reduce (round 1's form): N log2(64) adds, but no select / broadcast code -- kept
 // for the FIT instantiations, which run once per winner and whose register budget (they also
 // carry the fit's output pointers) the halving form's temporaries overflowed into scratch.
@@ -217,6 +200,73 @@ __device__ __forceinline__ double dpp1(double src) {
 #define DPP_WAVE_SHR1 0x138
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
+
+// The exchange of a halving round.  Distances 32 and 16 are what v_permlane32_swap / v_permlane16_swap
+// (gfx950) do natively: with the kept value in the first operand and the handed-over one in the second,
+// the swap leaves (own, partner's) of the half each lane keeps in the two registers -- no selects, no
+// LDS.  Distances 8, 4, 2, 1 stay inside a row of 16 lanes: DPP moves (row_ror:8, two bank-masked
+// row shifts by 4, quad_perm).  A ds_bpermute round trip is ~35 ns for a lone wave, a DPP move ~2 ns;
+// six rounds an iteration (tools/scan_sections.py: 1438 of 7175 cycles at T = 213 before).  The
+// operands of every add are the same as before, so results are bit-identical.
+#ifndef LDSR_RED_DPP
+#define LDSR_RED_DPP 1
+#endif
+template <int D>
+__device__ __forceinline__ int xor_dpp_w(int v) {
+    static_assert(D == 1 || D == 2 || D == 4 || D == 8, "row-local distances only");
+    if constexpr (D == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    else if constexpr (D == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);    // row_ror:8
+    else {   // banks 0, 2 read four lanes up, banks 1, 3 four lanes down
+        const int t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHL(4), 0xF, 0x5, false);
+        return __builtin_amdgcn_update_dpp(t, v, DPP_ROW_SHR(4), 0xF, 0xA, false);
+    }
+}
+template <int D>
+__device__ __forceinline__ double xor_dpp(double v) {
+    return __hiloint2double(xor_dpp_w<D>(__double2hiint(v)), xor_dpp_w<D>(__double2loint(v)));
+}
+template <int N, int D>
+__device__ __forceinline__ void red_rounds(double *x, int lane) {
+    if constexpr (D >= 1) {
+        constexpr int NK = (N + 1) / 2, NF = N - NK;
+        if constexpr (LDSR_RED_DPP && D >= 16) {
+#pragma unroll
+            for (int i = 0; i < NK; i++) {
+                const double a = x[i], b = (i < NF) ? x[NK + i] : 0.0;   // (an odd count leaves one padded slot)
+                unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+                unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+                if constexpr (D == 32) {
+                    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+                    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+                    alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+                } else {
+                    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+                    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+                    alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+                }
+                x[i] = __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
+            }
+        } else {
+            const bool up = (lane & D) != 0;
+            double snd[NK], kp[NK];
+#pragma unroll
+            for (int i = 0; i < NK; i++) {
+                const double hi = (i < NF) ? x[NK + i] : 0.0;
+                snd[i] = up ? x[i] : hi;
+                kp[i] = up ? hi : x[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NK; i++) {
+                if constexpr (LDSR_RED_DPP && D <= 8) snd[i] = xor_dpp<D>(snd[i]);
+                else snd[i] = __shfl_xor(snd[i], D, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < NK; i++) x[i] = kp[i] + snd[i];
+        }
+        red_rounds<NK, D / 2>(x, lane);
+    }
+}
 
 // partner matrix of a scan round; identity where the partner lane does not exist
 template <int CTRL, int RM>
@@ -401,6 +451,21 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
     }
 }
 
+// LDSR_SCAN_TIMING (tools/scan_sections.py): shader-clock cycles of every section of an EM iteration,
+// summed over the cell's iterations and left in the first eight slots of the cell's likelihood trace
+#ifdef LDSR_SCAN_TIMING
+#define SCAN_TICK(k)                                                          \
+    {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter();         \
+        tick_[k] += now_ - last_;                                             \
+        last_ = now_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
+#else
+#define SCAN_TICK(k)
+#endif
+
 template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
 __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
@@ -498,8 +563,13 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     // 1.537 -> 1.41 ms, cfg3 6.08 -> 5.24, cfg5 9.18 -> 8.47, masked (1,2) 1.71 -> 1.61.
     constexpr bool EBA = (L <= 16) && !EBR && LDSR_EB_ALIAS;
     double Jfin = 0.0;      // FIT: J[T-1] of src/EM.cpp:98 (the backward recursion itself uses 0)
+#ifdef LDSR_SCAN_TIMING
+    unsigned long long tick_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
+        SCAN_TICK(7)       // M-step, theta broadcast, loop overhead
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
         const double A2 = A * A, C2 = C * C;
         const double rR = fast_rcp(R);
@@ -604,6 +674,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             prenorm(M);
         }
 
+        SCAN_TICK(0)       // F1
         // ------------------------------------------------ forward scan (inclusive, by lane)
         // rows of 16 lanes: Kogge-Stone by DPP row shifts (identity outside the row) ...
         M = pmul(M, pdpp<DPP_ROW_SHR(1), 0xF>(M));
@@ -661,6 +732,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             Xp = x_e * rd;
         }
 
+        SCAN_TICK(1)       // forward scan
         // ------------------------------------------------ F2: serial re-run from the exact entry
         // log-determinant: running product of the observed Sigma_t, folded into (mantissa,
         // exponent) every 8 steps so that it can neither overflow nor underflow (:122 sums logs)
@@ -750,6 +822,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         // (1 of n_iter sweeps) but every iteration saves 6 dependent cross-lane rounds.
         const double lsp = fma((double)sexp, 0.69314718055994530942, log_pos(sprod));
 
+        SCAN_TICK(2)       // F2
         // ------------------------------------------------ B1: compose the reverse affine maps
         auto b1 = [&](int j) {
             const double J = Jv[j];
@@ -814,6 +887,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         double Xn = dppd<DPP_WAVE_SHL1, 0xF>(Xt, G);
         double Vn = dppd<DPP_WAVE_SHL1, 0xF>(Vt, H);
 
+        SCAN_TICK(3)       // B1 + reverse scan
         // ------------------------------------------------ B2: serial reverse re-run + M-step sums
         double aSyx = 0.0, aSxx = 0.0, aTx1x = 0.0, aPall = 0.0, term = 0.0, aSsq = 0.0;
         double aSxv[QQ], aTx1u[PP], aTux[PP];
@@ -935,6 +1009,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             }
         }
         const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
+        SCAN_TICK(4)       // B2
         Sums<PP, QQ> S;
         double ssq = 0.0;
         {
@@ -1011,6 +1086,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                 }
             }
         }
+        SCAN_TICK(5)       // reduction, likelihood
         if constexpr (FIT) {
             it = 1;
             break;
@@ -1037,6 +1113,10 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             if (prm.liks && prm.liks_nanfill)
                 for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
             prm.n_iter[cell] = it;
+#ifdef LDSR_SCAN_TIMING
+            if (prm.liks && prm.niter >= 8)
+                for (int k = 0; k < 8; k++) prm.liks[(long)cell * prm.niter + k] = (double)tick_[k];
+#endif
         }
         prm.lik[cell] = lik;
         prm.status[cell] = (interrupted && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
