@@ -514,8 +514,14 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     constexpr bool BUREG = STEADY && HREG && !LDSR_W64_BU_RECOMPUTE;
     double buv[BUREG ? L : 1];
     int wit = 0;             // wave-uniform iteration count (interrupt poll)
+#ifdef LDSR_SCAN_TIMING
+    unsigned long long tick_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+    const unsigned long long real0_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
 
     while (__any(alive)) {
+        SCAN_TICK(7)       // M-step, stop rule, loop
         const double A = th.A, C = th.C, Q = th.Q, R = th.R;
         const double A2 = A * A, C2 = C * C;
         const double rR = fast_rcp(R);
@@ -538,6 +544,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         // good nor lose its mantissa on the way up to 1).
         double x_t1 = th.mu1, v_t1 = th.V1, c_first = 1.0;
         double lS[LEAD ? 7 + 4 * PP : 1];
+        // Wide inputs: the lead's 7 + 4 p sums are reduced right here (same tree, same totals), so that
+        // only the one or two slots a lane keeps stay live through the sweeps -- next to the sweeps'
+        // own 5 + q + 2 p accumulators they would not fit in the registers of two waves per SIMD.
+        constexpr bool LSPLIT = LEAD && (PP + QQ > 8);
+        constexpr int NLS = 7 + 4 * PP;
+        double lt0 = 0.0, lt1 = 0.0;
         if constexpr (LEAD) {
             const int nA = (lead + LPC - 1) / LPC;
             const int tA = vl * nA;                                  // first lead step of this lane
@@ -620,6 +632,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 Xl = Xl1; Vl = Vl1; c = c1;
             }
             c_first = shfl_d(c_first, hbase);       // c_0 (lane 0 of the cell)
+            if constexpr (LSPLIT) {
+                static_assert(NLS <= 2 * LPC, "two slots per lane");
+                red_rounds<NLS, LPC / 2>(lS, lane);
+                lt0 = lS[0];
+                lt1 = lS[NLS > LPC ? 1 : 0];
+            }
         }
 
         // ------------------------------------------------ outputs of the sweeps (either form)
@@ -766,6 +784,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
         }
 
+        SCAN_TICK(0)       // iteration constants, transient block, verdict
         if constexpr (STEADY) if (__builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
             // ============================================ steady sweeps over t = NTR .. T-1
             // Lane K0-1 keeps only its predicated step L-1 (= step NTR); lanes K0.. their whole chunks.
@@ -835,6 +854,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
             if constexpr (LPC == 64) SSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
 #undef SSCAN_ROUND
+            SCAN_TICK(1)   // steady F1
             double Xp = fma(al, X_tr, bl);                           // after this lane's steps
             Xp = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xp);
             if (vl == 0) Xp = X_tr;
@@ -885,6 +905,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 }
                 if (tail_s) f2s(L - 1, buLast);
             }
+            SCAN_TICK(2)   // forward scan, steady F2
             // B2's first reads of the image are issued here, ahead of the reverse scan
             constexpr bool PRET2 = KP <= 4;
             double Vt[2 * KP], V[PF][2 * KP];
@@ -919,6 +940,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #ifdef LDSR_STEADY_DEBUG
             dbg[5] = Xn; dbg[8] = G;
 #endif
+            SCAN_TICK(3)   // reverse composite and scan
             // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
             zero_sums();
             auto b2s = [&](int j, const double (&w)[2 * KP]) {
@@ -951,6 +973,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
                 }
             }
+            SCAN_TICK(4)   // steady B2
             // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
             // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
             const int N = T - NTR;                                   // steps NTR .. T-1
@@ -1007,6 +1030,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
             }
         }
+        SCAN_TICK(5)       // closed-form variance sums, transient block backwards
         if (!st && STEADY && !alive) zero_sums();     // (an idle half: nothing ran)
         if (!st && (!STEADY || alive)) {
 #ifndef LDSR_STEADY_ONLY_EXPERIMENT   // (timing experiment: no fallback at all -- results wrong for slow cells)
@@ -1022,15 +1046,16 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 #endif
         }
 
+        SCAN_TICK(6)       // the generic sweeps (fallback cells)
         // ------------------------------------------------ one reduction per half, M-step, stop rule
         Sums<PP, QQ> S;
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);
             constexpr int NT = NB + QQ + 2 * PP;                     // the sweeps' sums
-            constexpr int NR = NT + (LEAD ? 7 + 4 * PP : 0);         // + the lead's
-            static_assert(NR <= 2 * LPC, "reduction gather handles two slots per lane");
+            constexpr int NR = NT + (LEAD && !LSPLIT ? 7 + 4 * PP : 0);   // + the lead's (unless reduced already)
+            static_assert(NR <= 3 * LPC, "reduction gather handles three slots per lane");
             double red[NR];
-            if constexpr (LEAD) {
+            if constexpr (LEAD && !LSPLIT) {
 #pragma unroll
                 for (int i = 0; i < 7 + 4 * PP; i++) red[NT + i] = lS[i];
             }
@@ -1046,10 +1071,13 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             {
                 // (more values than lanes -- 17 or 18 sums on the 16 lanes of a quad cell -- leave two
                 // live slots per lane)
-                const double t0 = red[0], t1 = red[1];
+                // (... and the 30 + 39 sums of p = q = 8 with a lead three on 32 lanes)
+                const double t0 = red[0], t1 = red[1], t2 = red[NR > 2 * LPC ? 2 : 0];
 #pragma unroll
-                for (int i = 0; i < NR; i++)
-                    red[i] = shfl_d(red_slot(i, NR, LPC) == 0 ? t0 : t1, hbase | red_home(i, NR, LPC));
+                for (int i = 0; i < NR; i++) {
+                    const int sl = red_slot(i, NR, LPC);
+                    red[i] = shfl_d(sl == 0 ? t0 : sl == 1 ? t1 : t2, hbase | red_home(i, NR, LPC));
+                }
             }
             S.X0 = shfl_d(X0v, hbase);               // :218
             S.V0 = shfl_d(V0v, hbase);               // :219
@@ -1059,7 +1087,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 // (delta, eps) at the tail's first step close the lead's sums; mu1 / V1 come from t = 0
                 const double dlt = S.X0 - x_t1, eps = S.V0 - v_t1;
                 const double d2e = fma(dlt, dlt, eps);
-                const double *l = red + NT;
+                if constexpr (LSPLIT) {
+#pragma unroll
+                    for (int i = 0; i < NLS; i++)
+                        lS[i] = shfl_d(red_slot(i, NLS, LPC) == 0 ? lt0 : lt1, hbase | red_home(i, NLS, LPC));
+                }
+                const double *l = LSPLIT ? lS : red + NT;
                 red[2] += (l[0] + l[1]) + fma(2.0 * dlt, l[2], d2e * l[3]);                 // sum Xs^2 + Vs
                 red[1] += l[4] + fma(dlt, l[5], fma(d2e, l[6], A * l[1]));                  // sum Xs' Xs + Vs' J
 #pragma unroll
@@ -1086,6 +1119,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;   // :113-124
             if (neg) lik = NAN;
         }
+        SCAN_TICK(8)       // reduction, likelihood
         int abort_now = 0;
         if (prm.abort && ((++wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
             abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
@@ -1103,6 +1137,11 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 prm.n_iter[cell] = it;
                 prm.lik[cell] = lik;
                 prm.status[cell] = (abort_now && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
+#ifdef LDSR_SCAN_TIMING
+                tick_[9] = __builtin_amdgcn_s_memrealtime() - real0_;      // -> shader clock = cycles / this x 100 MHz
+                if (prm.liks && prm.niter >= 10)
+                    for (int k_ = 0; k_ < 10; k_++) prm.liks[(long)cell * prm.niter + k_] = (double)tick_[k_];
+#endif
             }
 #ifdef LDSR_STEADY_DEBUG
             if (prm.liks && cell == c0 && 16 + 12 * LPC <= prm.niter)
@@ -1210,7 +1249,7 @@ struct PairPlan {
     int wpb = 0;        // waves per workgroup
     bool ok = false;
 };
-PairPlan pair_plan(int T, int PP, int QQ, int lpc);
+PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form = false);
 
 template <int L, int LPC>
 hipError_t launch_em_pair_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int wpb, bool queue,

@@ -103,7 +103,7 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 // and eight strips must fit 160 KiB -- at lpc = 32: (1,2): every L; (1,4): L <= 29; (2,4), (4,2):
 // L <= 27; (4,4): L <= 25.  Same-box A/B at 8192 cells: with 7 or 6 waves per CU (and the coarser
 // workgroup count) it is 20-25 % SLOWER than the one-cell-per-wave kernel, with 8 it is 10-15 % faster.
-PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
+PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
     PairPlan p;
     p.lpc = lpc;
     if (lpc == 64) {
@@ -121,7 +121,12 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
         p.ok = true;
         return p;
     }
-    if ((lpc != 32 && lpc != 16) || PP > 4 || QQ > 4 || T <= 64) return p;
+    // Wide inputs (padded p or q = 8) exist as the two-cells-per-wave LEAD form only: the tail of a
+    // closed-form lead in chunks of <= 16 steps (the generic sweeps of long chunks do not fit the
+    // registers of two waves per SIMD at q = 8; the lead itself never touches v_t).
+    const bool wide = PP > 4 || QQ > 4;
+    if ((lpc != 32 && lpc != 16) || PP > 8 || QQ > 8 || T <= 64) return p;
+    if (wide && !(lead_form && lpc == 32 && T <= 512)) return p;
     // every chunk length from 3 to 32: the shortest one wastes no lanes (four cells per wave: from 5)
     // (lanes 0 .. rp-1 own L steps, the others L-1: needs 1 <= rp <= nl)
     for (int L = (lpc == 16 ? 5 : 3); L <= 32; L++) {
@@ -132,7 +137,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
     if (!p.L) return p;
     const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ, lpc) * sizeof(double);
     const size_t strip = (size_t)pair_strip_doubles(p.L) * sizeof(double);
-    if (img + 8 * strip > kLdsBytes) return p;
+    if (img + (wide ? 4 : 8) * strip > kLdsBytes) return p;     // (wide: four waves per workgroup may have to do)
     p.wpb = 8;
     p.ok = true;
     return p;
@@ -146,7 +151,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc) {
 // 3.42 -> 3.29 ms; config 2's image allows one workgroup per CU only.  LDSR_PAIR_WPB=8 keeps
 // eight (A/B hook).
 int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
-    const PairPlan p = pair_plan(T, PP, QQ, lpc);
+    const PairPlan p = pair_plan(T, PP, QQ, lpc, lead > 0);
     if (!p.ok) return 0;
     if (lpc == 64) return p.wpb;
     static const int wpb_env = [] { const char *e = getenv("LDSR_PAIR_WPB"); return e ? atoi(e) : 0; }();
@@ -156,24 +161,27 @@ int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
                         (lead > 0 ? (size_t)pair_lead_doubles(lead, lpc, PP) : 0) +
                         (lead == 0 && pair_steady(p.L, lpc, PP, QQ) ? (size_t)pair_tri_doubles(PP, QQ, lpc) : 0)) * sizeof(double);
     // (the runtime keeps some LDS per workgroup for itself: leave 1 KiB per workgroup free)
-    return (8 / w) * (lds + 1024) <= kLdsBytes ? w : 8;
+    if ((8 / w) * (lds + 1024) <= kLdsBytes) return w;
+    // (wide LEAD forms whose image, strips and lead leave no room for eight waves: ONE workgroup of four)
+    const size_t lds8 = lds + (size_t)(8 - w) * pair_strip_doubles(p.L) * sizeof(double);
+    return lds8 <= kLdsBytes ? 8 : w;
 }
 
-bool em_pair_supported(int T, int PP, int QQ, int lpc) { return pair_plan(T, PP, QQ, lpc).ok; }
+bool em_pair_supported(int T, int PP, int QQ, int lpc, bool lead_form) { return pair_plan(T, PP, QQ, lpc, lead_form).ok; }
 int em_pair_cells_per_block(int T, int PP, int QQ, int lpc, int lead) { return (64 / lpc) * em_pair_waves_per_block(T, PP, QQ, lpc, lead); }
-void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles) {
-    const PairPlan p = pair_plan(T, PP, QQ, lpc);
+void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles, bool lead_form) {
+    const PairPlan p = pair_plan(T, PP, QQ, lpc, lead_form);
     *L = p.L;
     *img_doubles = p.ok ? pair_image_doubles(p.L, PP, QQ, lpc) : 0;
 }
 void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead) {
-    const PairPlan p = pair_plan(T, PP, QQ, lpc);
+    const PairPlan p = pair_plan(T, PP, QQ, lpc, lead);
     snprintf(buf, len, "em_pair_kernel<%d, %d, %d, %d, %s, %s>", PP, QQ, p.L, lpc, queue ? "true" : "false", lead ? "true" : "false");
 }
 
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,
                           hipStream_t stream) {
-    PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc);     // (LEAD form: the tail's plan)
+    PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc, prm.lead > 0);     // (LEAD form: the tail's plan)
     if (!p.ok || !prm.img2 || (prm.lead > 0 && !prm.img3)) return hipErrorInvalidValue;
     p.wpb = em_pair_waves_per_block(prm.T - prm.lead, PP, QQ, lpc, prm.lead);
 #define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \

@@ -446,14 +446,15 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     // room for the pair family's images whatever runs in the end (the launch decides: member,
     // chunk length, a closed-form lead): the largest 32-lane image, and u_t of a lead of up to T steps
     L.img2_stride = 0; L.img2_L = 0; L.img3_stride = 0;
-    if (PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL) {
-        L.img2_stride = pair_image_doubles(32, PP, QQ, 32);
+    if (PP <= 8 && QQ <= 8 && algo != LDSR_ALGO_SERIAL) {
+        // (wide inputs: the LEAD form's tail only, chunks of <= 16 steps)
+        L.img2_stride = pair_image_doubles(PP <= 4 && QQ <= 4 ? 32 : 16, PP, QQ, 32);
         L.img3_stride = (long)(T + 32) * PP;
     }
     L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
     L.img3 = o; o = align256(o + sizeof(double) * (size_t)L.img3_stride * n_series);
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
-    if (PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 4);    // the pair family's smallest workgroup
+    if (PP <= 8 && QQ <= 8 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 4);    // the pair family's smallest workgroup
     L.max_blocks = n_cells / cpb + n_series + 1;
     L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
@@ -514,7 +515,8 @@ static bool pair_pays_with_early_stopping(int T, int PP, int QQ) {
 }
 
 static int lead_tail(int T, int PP, int QQ, int lead_steps) {
-    if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 4 || QQ > 4) return 0;
+    if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 8 || QQ > 8) return 0;
+    const bool wide = PP > 4 || QQ > 4;     // (two cells per wave, LEAD form only: kernels_scan.hip pair_plan)
     int tail = std::max(T - lead_steps, 80);
     tail = (tail + 15) / 16 * 16;
     static const int max_tail = [] { const char *e = getenv("LDSR_LEAD_MAX_TAIL"); return e ? atoi(e) : 512; }();
@@ -528,14 +530,14 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     auto fits = [&](int lp) {
         int Lc = 0;
         long img = 0;
-        em_pair_layout(tail, PP, QQ, lp, &Lc, &img);
+        em_pair_layout(tail, PP, QQ, lp, &Lc, &img, true);
         if (!img) return false;
-        const size_t lds = ((size_t)img + 8 * (size_t)pair_strip_doubles(Lc) +
+        const size_t lds = ((size_t)img + (wide ? 4 : 8) * (size_t)pair_strip_doubles(Lc) +
                             (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
         return lds <= 160 * 1024;
     };
     // (p = 3, 4 and tails beyond 256 steps: two cells per wave only)
-    return ((PP > 2 || tail > 256 || fits(16)) && fits(32)) ? tail : 0;
+    return ((PP > 2 || wide || tail > 256 || fits(16)) && fits(32)) ? tail : 0;
 }
 
 static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len,
@@ -548,8 +550,8 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
     if (!tail) return em_plan_impl(T, p, q, niter, tol, algo, buf, len, lead_steps < 0);
-    const int lpc = (PP <= 2 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
-    if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0, buf, len, true);
+    const int lpc = (PP <= 2 && QQ <= 4 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
+    if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0 || PP > 4 || QQ > 4, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
 }
 
@@ -645,7 +647,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // 0.62 (tools/fill_ab.sh) -- two cells per wave from 1/4 of the CUs (1024 cells), four from 3/8
     // (3072 cells).
     auto fills = [&](int Te, int lp, bool lead_form = false) {
-        if (!em_pair_supported(Te, PP, QQ, lp)) return false;
+        if (!em_pair_supported(Te, PP, QQ, lp, lead_form)) return false;
         const int c = (64 / lp) * 8;          // a CU's eight waves
         long wgs = 0;
         // (a slice of a multi-device call counts the whole call's cells: plan_off)
@@ -672,7 +674,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (was_auto && algo != LDSR_ALGO_SERIAL) {
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
-            if (PP <= 2 && tail <= 256 && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            if (PP <= 2 && QQ <= 4 && tail <= 256 && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }
@@ -707,7 +709,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         return fail(LDSR_EINVAL, "unknown algo");
     if (algo == LDSR_ALGO_SCAN && !em_scan_supported(T, PP, QQ))
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
-    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(Te, PP, QQ, 32))
+    if (algo == LDSR_ALGO_PAIR && !em_pair_supported(Te, PP, QQ, 32, lead > 0))
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
     if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
@@ -728,7 +730,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         L.img3_stride = 0;
     } else if (cpw) {       // the image of the member that runs (the room is for the largest)
         long sz = 0;
-        em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz);
+        em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz, lead > 0);
         L.img2_NL = lpc;
         L.lead = lead;
     } else {
@@ -750,7 +752,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // cells of the series) -- waves pull cells from the per-series queue, so a wave whose cell
     // converges early takes the next one instead of idling.
     const bool use_queue = (algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol)) ||
-                           (cpw && tol > 0.0);
+                           (cpw && (tol > 0.0 || (lead > 0 && (PP > 4 || QQ > 4))));   // (wide LEAD forms: work-queue schedule only)
     std::vector<int> bs, bc, bn;
     for (int s = 0; s < n_series; s++)
         for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {

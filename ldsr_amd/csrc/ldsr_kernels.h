@@ -75,10 +75,10 @@ bool em_scan_queue_only(int T, int PP, int QQ);     // shapes compiled with the 
 bool em_scan_supported(int T, int PP, int QQ);
 int em_scan_cells_per_block(int T, int PP, int QQ);
 // two (lpc = 32) or four (lpc = 16) cells per wave (em_pair_impl.h): T <= lpc * 32, padded p, q <= 4
-bool em_pair_supported(int T, int PP, int QQ, int lpc);
+bool em_pair_supported(int T, int PP, int QQ, int lpc, bool lead_form = false);   // lead_form: T = the tail of a closed-form lead
 int em_pair_cells_per_block(int T, int PP, int QQ, int lpc, int lead = 0);   // T: the steps the sweeps work on
 int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead = 0);
-void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles);
+void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles, bool lead_form = false);
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue, hipStream_t stream);
 void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead = false);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)

@@ -72,6 +72,12 @@ def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
     (1000, 1, 2, 1, 560, True, 0),         # tails of 257..512 steps: two cells per wave, chunks of <= 16 steps
     (2000, 2, 4, 2, 1500, False, 6),
     (1500, 3, 3, 1, 1100, True, 0),
+    # wide inputs (padded p or q = 8): the two-cells-per-wave LEAD form with the work-queue schedule
+    (1024, 4, 8, 1, 816, False, 0),        # config 3's shape with the paleo mask
+    (813, 7, 7, 2, 733, True, 3),          # the known-answer problem's width (p = q = 7) on the Nakhon Phanom length
+    (1000, 1, 8, 1, 900, False, 0),
+    (1200, 6, 2, 1, 1000, False, 0),
+    (2000, 3, 5, 1, 1500, True, 0),        # tail of 500 steps
 ])
 def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
     Y, U, V, off, th0 = _grid(T, p, q, S, lead, 8192 // S, 60 + T, holes, stagger)
@@ -97,7 +103,11 @@ def test_lead_plan_and_limits(eng):
     assert plan(813, 3, 3, 760)[1] == "em_pair_kernel<4, 4, 3, 32, false, true>"           # p = 3,4: two cells per wave
     assert plan(1000, 1, 2, 600)[1] == "em_pair_kernel<1, 2, 13, 32, false, true>"         # tail of 400 steps
     assert plan(2000, 1, 4, 1500, 1e-5) == (3, "em_pair_kernel<1, 4, 16, 32, true, true>")
-    for args in ((1000, 1, 2, 100), (1000, 1, 2, 480), (1000, 5, 2, 900), (1000, 1, 8, 900)):
+    # wide inputs (padded p or q = 8): two cells per wave, work queue
+    assert plan(1000, 5, 2, 900) == (3, "em_pair_kernel<8, 2, 4, 32, true, true>")
+    assert plan(1024, 4, 8, 816)[1] == "em_pair_kernel<4, 8, 7, 32, true, true>"             # config 3's shape, paleo mask
+    assert plan(813, 7, 7, 733, 1e-5)[1] == "em_pair_kernel<8, 8, 3, 32, true, true>"
+    for args in ((1000, 1, 2, 100), (1000, 1, 2, 480), (1000, 9, 2, 900), (1000, 1, 12, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
     assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
     assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false, false>"

@@ -35,8 +35,45 @@ def run(T, p, q, cells, lead, niter=200):
             print(f"    {n:14s} {med[k]:8.0f}  {100 * med[k] / tot:5.1f} %")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("SECTIONS_PAIR"):
     run(85, 7, 7, 50, 0)
     run(213, 3, 3, 50, 0)
     run(813, 3, 3, 50, 733)
     run(813, 3, 3, 50, 0)
+
+
+PAIR_NAMES = ["consts+transient", "steady F1", "scan+steady F2", "rev composite+scan", "steady B2",
+              "closed form+transient back", "generic fallback", "M-step+stop+loop", "reduce+lik"]
+
+
+def run_pair(T=1024, p=1, q=2, cells=4096, niter=100):
+    """BASELINE config 2 through AUTO (the two-cells-per-wave kernel with steady sweeps): cycles per
+    iteration of a wave, two waves per SIMD -- shares, not latencies."""
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal((p, T))
+    v = rng.standard_normal((q, T))
+    x = np.zeros(T)
+    for t in range(1, T):
+        x[t] = 0.8 * x[t - 1] + 0.3 * u[0, t - 1] + 0.3 * rng.standard_normal()
+    y = x + 0.4 * v[0] + 0.3 * rng.standard_normal(T)
+    th0 = api.make_init_packed(p, q, cells, seed=5)
+    r = api.em_batch(y[None, :], u, v, th0, niter=niter, tol=0.0, return_liks=True)
+    tk = r["liks"][:, :10] / niter
+    med = np.mean(tk, axis=0)
+    tot = med[:9].sum()
+    print(f"shader clock while the kernel runs: {100.0 * tot / med[9]:.0f} MHz (s_memtime cycles per s_memrealtime tick of 10 ns)")
+    print(f"pair kernel T={T} p={p} q={q} cells={cells}: {tot:8.0f} cycles / iteration (mean over cells)")
+    tot_c = tk[:, :9].sum(axis=1)
+    pc = np.percentile(tot_c, [50, 90, 99, 100])
+    print("    cycles / iteration of a cell's wave: median %.0f  p90 %.0f  p99 %.0f  max %.0f" % tuple(pc))
+    slow = tot_c >= np.percentile(tot_c, 99)
+    print("    slowest 1 %% of the cells: generic fallback %.0f cycles / iteration (%.0f %% of their time), n_iter all %d"
+          % (tk[slow, 6].mean(), 100 * tk[slow, 6].mean() / tot_c[slow].mean(), niter))
+    order = [7, 0, 1, 2, 3, 4, 5, 6, 8]
+    names = dict(zip([0, 1, 2, 3, 4, 5, 6, 7, 8], PAIR_NAMES))
+    for k in order:
+        print(f"    {names[k]:28s} {med[k]:8.0f}  {100 * med[k] / tot:5.1f} %")
+
+
+if __name__ == "__main__" and os.environ.get("SECTIONS_PAIR"):
+    run_pair()
