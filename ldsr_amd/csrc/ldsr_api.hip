@@ -662,6 +662,11 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // LEAD in ms, tools/lead_fill_ab.sh: T = 2000 (1,4) 1536 cells 1.94 -> 1.40, 3072 3.79 -> 1.47;
         // T = 4000 (2,2) 1536 cells 8.27 -> 2.47; T = 813 (3,3) 1536 0.92 -> 0.85, 3072 1.42 -> 1.27);
         // with early stopping only for long leads (2048 cells: T = 2000 2.81 -> 2.23, T = 813 2.85 -> 3.09)
+        // from T = 1536 on the scan kernel's chunks are 28..32 steps long (and its image may live in global
+        // memory): there the lead pays whatever the launch size -- 50 lone cells, niter = 200, scan -> LEAD in
+        // ms: T = 2000 (1,4) 3.61 -> 2.44, (3,5) 17.1 -> 3.96, T = 4000 (2,2) 6.30 -> 4.95; at T = 1100..1300
+        // it is a toss-up (1.40 -> 1.48, 1.81 -> 2.07, 2.17 -> 1.78)
+        if (lead_form && T >= 1536) return true;
         if (lead_form && (tol == 0.0 || lead_hint >= 1024))
             return wgs * (lp == 16 ? 16 : 8) >= 3 * cus;
         return wgs * 8 >= 7 * cus;

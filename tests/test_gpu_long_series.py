@@ -38,9 +38,14 @@ def test_long_series_on_the_multi_wave_scan_kernel(T, p, q, mask):
     assert np.array_equal(r["n_iter"], ref[2]), (r["n_iter"], ref[2])
     assert parity_close(r["lik"], ref[1], RTOL, ATOL)
     assert parity_close(r["theta"], ref[0], RTOL, ATOL)
-    # AUTO picks the scan kernel for these lengths and gives the very same bits
+    # AUTO picks the scan kernel for fully observed series of these lengths and gives the very same
+    # bits; a long all-missing lead it handles in closed form (the LEAD form of the pair family)
     a = ldsr_amd.em_batch(y, u, v, th0, niter=40, tol=1e-5)
-    assert np.array_equal(a["theta"], r["theta"]) and np.array_equal(a["n_iter"], r["n_iter"])
+    assert np.array_equal(a["n_iter"], r["n_iter"])
+    if mask == "dense":
+        assert np.array_equal(a["theta"], r["theta"])
+    else:
+        assert parity_close(a["lik"], ref[1], RTOL, ATOL) and parity_close(a["theta"], ref[0], RTOL, ATOL)
     # fixed iteration count (tol = 0) and the likelihood trace
     r0 = ldsr_amd.em_batch(y, u, v, th0[:3], niter=7, tol=0.0, algo=SCAN, return_liks=True)
     ref0 = _oracle_batch(y, u, v, th0[:3], 7, 0.0)
