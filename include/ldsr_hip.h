@@ -85,7 +85,9 @@ extern "C" {
 #define LDSR_ALGO_PAIR 3   /* the same scans with TWO cells per wavefront (one per 32-lane half):
                               65 <= T <= 1024, p, q <= 4, narrower ranges of T for the wider inputs
                               (ldsr_em_plan tells); AUTO's first choice where it applies -- with
-                              tol > 0 only for fully observed series */
+                              tol > 0 only for fully observed series.  Its LEAD form
+                              (a closed-form all-missing lead, tails <= 512 steps: ldsr_em_plan_lead)
+                              also exists for padded p or q = 8 */
 #define LDSR_ALGO_QUAD 4   /* FOUR cells per wavefront (one per 16-lane DPP row): 65 <= T <= 512,
                               p, q <= 4; AUTO's first choice there for launches that fill the device */
 
