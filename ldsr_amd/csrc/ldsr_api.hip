@@ -49,10 +49,11 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // One host-pinned flag for the whole library: kernels launched while a callback is registered
 // poll it; only the thread that entered the library from outside (t_poll) runs the callback.
 static struct {
-    std::mutex mu;
-    int (*cb)(void *) = nullptr;
-    void *arg = nullptr;
-    int *flag = nullptr;              // pinned, portable
+    std::mutex mu;                    // serialises registration and shutdown
+    // (read without the mutex by every EM entry and by the polling thread: atomics)
+    std::atomic<int (*)(void *)> cb{nullptr};
+    std::atomic<void *> arg{nullptr};
+    std::atomic<int *> flag{nullptr};  // pinned, portable
     std::atomic<int> active{0};       // external EM calls in flight
 } g_intr;
 static thread_local bool t_poll = false;     // this thread may run the callback
@@ -60,24 +61,29 @@ static thread_local bool t_worker = false;   // a library worker thread: never r
 
 extern "C" int ldsr_set_interrupt_callback(int (*callback)(void *), void *arg) {
     std::lock_guard<std::mutex> lk(g_intr.mu);
-    if (callback && !g_intr.flag) {
+    if (callback && !g_intr.flag.load()) {
         void *p = nullptr;
         HIPCHK(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
-        g_intr.flag = (int *)p;
-        *g_intr.flag = 0;
+        *(int *)p = 0;
+        g_intr.flag.store((int *)p);
     }
-    g_intr.cb = callback;
-    g_intr.arg = arg;
+    g_intr.arg.store(arg);
+    g_intr.cb.store(callback);
     return LDSR_OK;
 }
 
-static const int *intr_flag_for_kernels() { return g_intr.cb ? g_intr.flag : nullptr; }
-static bool intr_raised() { return g_intr.cb && g_intr.flag && *(volatile int *)g_intr.flag != 0; }
+static const int *intr_flag_for_kernels() { return g_intr.cb.load() ? g_intr.flag.load() : nullptr; }
+static bool intr_raised() {
+    int *f = g_intr.flag.load();
+    return g_intr.cb.load() && f && *(volatile int *)f != 0;
+}
 
 // Run the callback (external caller thread only); raise the flag if it asks to stop.
 static void intr_poll() {
-    if (!t_poll || !g_intr.cb || !g_intr.flag) return;
-    if (*(volatile int *)g_intr.flag == 0 && g_intr.cb(g_intr.arg)) *(volatile int *)g_intr.flag = 1;
+    int (*cb)(void *) = g_intr.cb.load();
+    int *f = g_intr.flag.load();
+    if (!t_poll || !cb || !f) return;
+    if (*(volatile int *)f == 0 && cb(g_intr.arg.load())) *(volatile int *)f = 1;
 }
 
 // RAII around an external EM entry: the outermost call on a non-worker thread becomes the poller
@@ -85,16 +91,18 @@ static void intr_poll() {
 struct IntrScope {
     bool owner = false;
     IntrScope() {
-        if (t_worker || t_poll || !g_intr.cb) return;
+        if (t_worker || t_poll || !g_intr.cb.load()) return;
         owner = true;
         t_poll = true;
-        if (g_intr.active.fetch_add(1) == 0 && g_intr.flag) *(volatile int *)g_intr.flag = 0;
+        int *f = g_intr.flag.load();
+        if (g_intr.active.fetch_add(1) == 0 && f) *(volatile int *)f = 0;
     }
     ~IntrScope() {
         if (!owner) return;
         // the last external call to leave clears the flag: a raised interrupt stops every call that
         // is in flight and is over once they have all returned
-        if (g_intr.active.fetch_sub(1) == 1 && g_intr.flag) *(volatile int *)g_intr.flag = 0;
+        int *f = g_intr.flag.load();
+        if (g_intr.active.fetch_sub(1) == 1 && f) *(volatile int *)f = 0;
         t_poll = false;
     }
 };
@@ -314,10 +322,10 @@ extern "C" void ldsr_shutdown(void) {
     }
     {
         std::lock_guard<std::mutex> lk(g_intr.mu);
-        if (g_intr.flag && g_intr.active.load() == 0) {
-            (void)hipHostFree(g_intr.flag);
-            g_intr.flag = nullptr;
-            g_intr.cb = nullptr;
+        if (g_intr.flag.load() && g_intr.active.load() == 0) {
+            g_intr.cb.store(nullptr);
+            (void)hipHostFree(g_intr.flag.load());
+            g_intr.flag.store(nullptr);
         }
     }
     std::lock_guard<std::mutex> lk(g_arena_mu);
