@@ -53,6 +53,9 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY_PF2        // ... and of the strip reads in F2
 #define LDSR_STEADY_PF2 6
 #endif
+#ifndef LDSR_LEAD_CLOSED_VAR    // LEAD pass 1: multipliers and variance offset of a lane's steps in closed form
+#define LDSR_LEAD_CLOSED_VAR 1
+#endif
 #ifndef LDSR_STEADY_SBMASK     // what may still cross the per-step scheduling barriers (0x2 VALU | 0x4 SALU)
 #define LDSR_STEADY_SBMASK 0x6
 #endif
@@ -560,6 +563,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             // 50 lone cells 1.46 -> 1.36, (4,8) T = 1024 5.55 -> 5.30; four cells per wave lose 6 % with it)
             constexpr bool LPF = LPC == 32;
             double al = 1.0, bl = 0.0, a2l = 1.0, ql = 0.0;
+            bool var_closed = false;
+            double geo = 0.0, geo2 = 0.0;
             {
                 double un[PP];
 #pragma unroll
@@ -578,9 +583,33 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                         for (int p_ = 0; p_ < PP; p_++) un[p_] = lup[(long)jn * LPC * PP + p_];
                     }
                     bl = fma(A, bl, bu);
-                    ql = fma(A2, ql, Q);
-                    al *= A;
-                    a2l *= A2;
+                    if constexpr (!LDSR_LEAD_CLOSED_VAR) {
+                        ql = fma(A2, ql, Q);
+                        al *= A;
+                        a2l *= A2;
+                    }
+                }
+            }
+            if constexpr (LDSR_LEAD_CLOSED_VAR) {
+                // the multipliers and the variance offset of the lane's nj steps do not need the loop:
+                // al = A^nj (binary powering), a2l = (A^2)^nj, ql = Q (1 - a2l) / (1 - A^2) -- three of the
+                // pass's five operations per step.  Near |A| = 1 the quotient loses digits: there the sum
+                // is formed term by term as before.
+                double pa = A, pa2 = A2;
+#pragma unroll
+                for (int bit = 0; bit < 10; bit++) {          // nj <= 8192 / 16
+                    if ((nj >> bit) & 1) { al *= pa; a2l *= pa2; }
+                    pa *= pa; pa2 *= pa2;
+                }
+                const double omA2 = 1.0 - A2;
+                var_closed = fabs(omA2) > 0.0009765625;
+                if (var_closed) {
+                    const double romA2 = fast_rcp(omA2);
+                    geo = (1.0 - a2l) * romA2;                       // 1 + A^2 + ... + A^(2 (nj - 1))
+                    ql = Q * geo;
+                    geo2 = ((double)nj - geo) * romA2;               // sum_j of the partial geometric sums
+                } else {
+                    for (int j = 0; j < nj; j++) ql = fma(A2, ql, Q);
                 }
             }
             // inclusive scan of both affine maps over the cell's lanes
@@ -604,6 +633,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             Xl = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xl);                       // entry of this lane
             Vl = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, Vl);
             if (vl == 0) { Xl = th.mu1; Vl = th.V1; }
+            const double Vl_entry = Vl;
             const double rV1 = fast_rcp(v_t1);
             // d = A^(t1 - t) at this lane's first step, as m 2^e (|A| clamped away from 0: beyond
             // a few steps the true value is below 1e-300 anyway)
@@ -615,10 +645,14 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             double dm = exp2(xl2 - ef);
             int de = (int)ef;
             if (As < 0.0 && (k0 & 1)) dm = -dm;
+            // (1 / Vp_t1 rides in the mantissa: one multiplication per step less)
+            dm *= rV1;
+            de += __builtin_amdgcn_frexp_exp(dm);
+            dm = __builtin_amdgcn_frexp_mant(dm);
 #pragma unroll
             for (int i = 0; i < 7 + 4 * PP; i++) lS[i] = 0.0;
             // pass 2: the data sums; c = c_t, c1 = c_{t+1}
-            double c = __builtin_amdgcn_ldexp(dm, de) * (Vl * rV1);
+            double c = __builtin_amdgcn_ldexp(dm, de) * Vl;
             c_first = c;
             double un2[PP];
 #pragma unroll
@@ -639,10 +673,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 }
                 const double Xl1 = fma(A, Xl, bu), Vl1 = fma(A2, Vl, Q);
                 dm *= rA;
-                if ((j & 7) == 7) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
-                const double c1 = __builtin_amdgcn_ldexp(dm, de) * (Vl1 * rV1);
+                // (every 4 steps: the compiler unrolls this loop by four, where (j & 3) == 3 is a constant of
+                // each copy -- every 8 cost three selects per renormalisation; exact either way)
+                if ((j & 3) == 3) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
+                const double c1 = __builtin_amdgcn_ldexp(dm, de) * Vl1;
                 lS[0] = fma(Xl, Xl, lS[0]);                   // sum Xp^2
-                lS[1] += Vl;                                  // sum Vp
+                if constexpr (!LDSR_LEAD_CLOSED_VAR) lS[1] += Vl;   // sum Vp
                 lS[2] = fma(c, Xl, lS[2]);                    // sum c Xp
                 lS[3] = fma(c, c, lS[3]);                     // sum c^2
                 lS[4] = fma(Xl1, Xl, lS[4]);                  // sum Xp_{t+1} Xp_t
@@ -656,6 +692,15 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     lS[7 + 3 * PP + p_] = fma(c, ul[p_], lS[7 + 3 * PP + p_]);    // sum c_t u_t
                 }
                 Xl = Xl1; Vl = Vl1; c = c1;
+            }
+            if constexpr (LDSR_LEAD_CLOSED_VAR) {
+                // sum of Vp over the lane's steps from its entry value V_e:  Vp_j = A^(2j) V_e + Q (1 + .. + A^(2(j-1)))
+                if (var_closed) {
+                    lS[1] = fma(Vl_entry, geo, Q * geo2);
+                } else {
+                    double vv = Vl_entry;
+                    for (int j = 0; j < nj; j++) { lS[1] += vv; vv = fma(A2, vv, Q); }
+                }
             }
             c_first = shfl_d(c_first, hbase);       // c_0 (lane 0 of the cell)
             if constexpr (LSPLIT) {
