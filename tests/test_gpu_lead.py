@@ -87,6 +87,24 @@ def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
         assert name.startswith("em_pair_kernel<") and name.endswith(", true>"), name   # the LEAD form ran
 
 
+def test_lead_near_a_unit_root(eng):
+    """|A| close to 1: the lead's closed forms in 1 / (1 - A^2) (em_pair_impl.h, LDSR_LEAD_CLOSED_VAR)
+    give way to term-by-term sums below |1 - A^2| = 2^-10; both sides of the switch, A = 1 exactly, a
+    negative and an explosive A against the oracle (few iterations, so that A stays where it was put)."""
+    Y, U, V, off, th0 = _grid(1000, 1, 2, 1, 900, 4096, 11)
+    # (a clearly explosive A -- 1.01: A^1800 = 6e7 -- is ill conditioned for the oracle and the kernels alike:
+    # both forms of the lead sit at 0.1 .. 1.2 of the bar there)
+    a0 = np.array([0.9999, 1.0, 0.99951, 0.99952, -0.9999, 1.0002, 0.9995117, 0.9995118, -1.0, 0.999999, 0.97])
+    th0[:, 0] = np.resize(a0, th0.shape[0])
+    for niter, tol in ((2, 0.0), (4, 0.0), (12, 1e-5)):
+        _run_and_check(eng, Y, U, V, off, th0, niter, tol, "A near 1, niter=%d" % niter)
+        assert _last_kernel().endswith(", true>")
+    Y, U, V, off, th0 = _grid(813, 3, 3, 1, 733, 4096, 12)          # two cells per wave
+    th0[:, 0] = np.resize(a0, th0.shape[0])
+    _run_and_check(eng, Y, U, V, off, th0, 3, 0.0, "A near 1, (3,3)")
+    assert _last_kernel().endswith(", true>")
+
+
 def test_lead_plan_and_limits(eng):
     from ldsr_amd import _lib
     L = _lib.lib()
