@@ -537,22 +537,24 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         // and  prod_{k=t}^{t1-1} J_k = A^(t1-t) Vp_t / Vp_t1 =: c_t  telescopes (J_k = A Vp_k / Vp_{k+1},
         // :98-100).  So with (delta, eps) = (Xs - Xp, Vs - Vp) at the first step t1 of the tail,
         //     Xs_t = Xp_t + c_t delta,   Vs_t = Vp_t + c_t^2 eps          for every t < t1,
-        // and the lead's share of every M-step sum (:180-193) is a polynomial in (delta, eps) whose
-        // coefficients are data sums of ONE forward pass -- no per-step storage, no backward pass,
-        // no 3x3 scan, ~20 fp64 operations per step against ~85 in the masked sweeps.  The sweeps
-        // below run on the tail [t1, T) from (Xp_t1, Vp_t1).  (tools/lead_closed_form_probe.py
-        // checks the formulas against the CPU oracle's smoother: 6e-16.)
+        // so the lead needs no per-step storage, no backward pass and no 3x3 scan: a first pass (here)
+        // carries (Xp, Vp) to t1, the sweeps below run on the tail [t1, T) from (Xp_t1, Vp_t1) and leave
+        // (delta, eps), and a second pass (after the sweeps) forms Xs_t as it goes and sums the lead's
+        // share of every M-step sum (:180-193) directly -- ~16 fp64 operations per step in all against ~85
+        // in the masked sweeps.  (Until round 3 the second pass ran BEFORE the sweeps and summed the
+        // coefficients of the polynomials in (delta, eps): 7 + 4 p sums and five more operations per step.
+        // tools/lead_closed_form_probe.py checks the formulas against the CPU oracle's smoother: 6e-16.)
         // Lane l of the cell owns lead steps [l nA, (l+1) nA); A^(t1-t) is carried as mantissa x
         // 2^exponent (it starts at 2^-thousands for the early lanes and must neither underflow for
         // good nor lose its mantissa on the way up to 1).
         double x_t1 = th.mu1, v_t1 = th.V1, c_first = 1.0;
-        double lS[LEAD ? 7 + 4 * PP : 1];
-        // Wide inputs: the lead's 7 + 4 p sums are reduced right here (same tree, same totals), so that
-        // only the one or two slots a lane keeps stay live through the sweeps -- next to the sweeps'
-        // own 5 + q + 2 p accumulators they would not fit in the registers of two waves per SIMD.
-        constexpr bool LSPLIT = LEAD && (PP + QQ > 8);
-        constexpr int NLS = 7 + 4 * PP;
-        double lt0 = 0.0, lt1 = 0.0;
+        constexpr int NLS = 5 + 2 * PP;       // sums of the lead's second pass
+        double lS[LEAD ? NLS : 1];
+        // what the first pass hands to the second: the lane's entry state, its weight A^(t1-t) / Vp_t1 as
+        // mantissa x 2^exponent, and the closed forms of its variance sums
+        double l_X = 0.0, l_V = 0.0, l_dm = 0.0, l_rA = 0.0, l_geo = 0.0, l_geo2 = 0.0;
+        int l_de = 0, l_nj = 0;
+        bool l_closed = false;
         if constexpr (LEAD) {
             const int nA = (lead + LPC - 1) / LPC;
             const int tA = vl * nA;                                  // first lead step of this lane
@@ -633,7 +635,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             Xl = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xl);                       // entry of this lane
             Vl = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, Vl);
             if (vl == 0) { Xl = th.mu1; Vl = th.V1; }
-            const double Vl_entry = Vl;
             const double rV1 = fast_rcp(v_t1);
             // d = A^(t1 - t) at this lane's first step, as m 2^e (|A| clamped away from 0: beyond
             // a few steps the true value is below 1e-300 anyway)
@@ -649,66 +650,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             dm *= rV1;
             de += __builtin_amdgcn_frexp_exp(dm);
             dm = __builtin_amdgcn_frexp_mant(dm);
-#pragma unroll
-            for (int i = 0; i < 7 + 4 * PP; i++) lS[i] = 0.0;
-            // pass 2: the data sums; c = c_t, c1 = c_{t+1}
-            double c = __builtin_amdgcn_ldexp(dm, de) * Vl;
-            c_first = c;
-            double un2[PP];
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) un2[p_] = (LPF && nj > 0) ? lup[p_] : 0.0;
-            for (int j = 0; j < nj; j++) {
-                double ul[PP];
-                double bu = 0.0;
-                if constexpr (!LPF) {
-#pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)j * LPC * PP + p_];
-                }
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) { ul[p_] = un2[p_]; bu = fma(th.B[p_], ul[p_], bu); }
-                if constexpr (LPF) {
-                    const int jn = min(j + 1, nj - 1);
-#pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)jn * LPC * PP + p_];
-                }
-                const double Xl1 = fma(A, Xl, bu), Vl1 = fma(A2, Vl, Q);
-                dm *= rA;
-                // (every 4 steps: the compiler unrolls this loop by four, where (j & 3) == 3 is a constant of
-                // each copy -- every 8 cost three selects per renormalisation; exact either way)
-                if ((j & 3) == 3) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
-                const double c1 = __builtin_amdgcn_ldexp(dm, de) * Vl1;
-                lS[0] = fma(Xl, Xl, lS[0]);                   // sum Xp^2
-                if constexpr (!LDSR_LEAD_CLOSED_VAR) lS[1] += Vl;   // sum Vp
-                lS[2] = fma(c, Xl, lS[2]);                    // sum c Xp
-                lS[3] = fma(c, c, lS[3]);                     // sum c^2
-                lS[4] = fma(Xl1, Xl, lS[4]);                  // sum Xp_{t+1} Xp_t
-                lS[5] = fma(c1, Xl, fma(c, Xl1, lS[5]));      // sum c_{t+1} Xp_t + c_t Xp_{t+1}
-                lS[6] = fma(c, c1, lS[6]);                    // sum c_t c_{t+1}
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) {
-                    lS[7 + p_] = fma(Xl1, ul[p_], lS[7 + p_]);                    // sum Xp_{t+1} u_t
-                    lS[7 + PP + p_] = fma(c1, ul[p_], lS[7 + PP + p_]);           // sum c_{t+1} u_t
-                    lS[7 + 2 * PP + p_] = fma(ul[p_], Xl, lS[7 + 2 * PP + p_]);   // sum u_t Xp_t
-                    lS[7 + 3 * PP + p_] = fma(c, ul[p_], lS[7 + 3 * PP + p_]);    // sum c_t u_t
-                }
-                Xl = Xl1; Vl = Vl1; c = c1;
-            }
-            if constexpr (LDSR_LEAD_CLOSED_VAR) {
-                // sum of Vp over the lane's steps from its entry value V_e:  Vp_j = A^(2j) V_e + Q (1 + .. + A^(2(j-1)))
-                if (var_closed) {
-                    lS[1] = fma(Vl_entry, geo, Q * geo2);
-                } else {
-                    double vv = Vl_entry;
-                    for (int j = 0; j < nj; j++) { lS[1] += vv; vv = fma(A2, vv, Q); }
-                }
-            }
+            c_first = __builtin_amdgcn_ldexp(dm, de) * Vl;
             c_first = shfl_d(c_first, hbase);       // c_0 (lane 0 of the cell)
-            if constexpr (LSPLIT) {
-                static_assert(NLS <= 2 * LPC, "two slots per lane");
-                red_rounds<NLS, LPC / 2>(lS, lane);
-                lt0 = lS[0];
-                lt1 = lS[NLS > LPC ? 1 : 0];
-            }
+            l_X = Xl; l_V = Vl; l_dm = dm; l_de = de; l_rA = rA; l_nj = nj;
+            l_closed = var_closed; l_geo = geo; l_geo2 = geo2;
         }
 
         // ------------------------------------------------ outputs of the sweeps (either form)
@@ -1118,17 +1063,76 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         }
 
         SCAN_TICK(6)       // the generic sweeps (fallback cells)
+        // ------------------------------------------------ LEAD, second pass: Xs_t = Xp_t + c_t delta as it goes
+        if constexpr (LEAD) {
+            const double dlt = shfl_d(X0v, hbase) - x_t1;            // Xs - Xp at the tail's first step
+            const double *lup = lu + (long)vl * PP;
+            constexpr bool LPF = LPC == 32;
+            const int nj = l_nj;
+            const double rA = l_rA;
+            double Xl = l_X, Vl = l_V, dm = l_dm;
+            int de = l_de;
+#pragma unroll
+            for (int i = 0; i < NLS; i++) lS[i] = 0.0;
+            double c = __builtin_amdgcn_ldexp(dm, de) * Vl;          // c_t, and c1 = c_{t+1}
+            double Xs = fma(c, dlt, Xl);
+            double un2[PP];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) un2[p_] = (LPF && nj > 0) ? lup[p_] : 0.0;
+            for (int j = 0; j < nj; j++) {
+                double ul[PP];
+                double bu = 0.0;
+                if constexpr (!LPF) {
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)j * LPC * PP + p_];
+                }
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) { ul[p_] = un2[p_]; bu = fma(th.B[p_], ul[p_], bu); }
+                if constexpr (LPF) {
+                    const int jn = min(j + 1, nj - 1);
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)jn * LPC * PP + p_];
+                }
+                const double Xl1 = fma(A, Xl, bu), Vl1 = fma(A2, Vl, Q);
+                dm *= rA;
+                // (every 4 steps: the compiler unrolls this loop by four, where (j & 3) == 3 is a constant of
+                // each copy -- every 8 cost three selects per renormalisation; exact either way)
+                if ((j & 3) == 3) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
+                const double c1 = __builtin_amdgcn_ldexp(dm, de) * Vl1;
+                const double Xs1 = fma(c1, dlt, Xl1);           // (the last one is Xs at t1 itself: c = 1)
+                lS[0] = fma(Xs, Xs, lS[0]);                   // sum Xs^2
+                if constexpr (!LDSR_LEAD_CLOSED_VAR) lS[1] += Vl;   // sum Vp
+                lS[2] = fma(c, c, lS[2]);                     // sum c^2          (Vs_t = Vp_t + c_t^2 eps)
+                lS[3] = fma(Xs1, Xs, lS[3]);                  // sum Xs_{t+1} Xs_t
+                lS[4] = fma(c, c1, lS[4]);                    // sum c_t c_{t+1}  (Vs_{t+1} J_t = A Vp_t + c_t c_{t+1} eps)
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    lS[5 + p_] = fma(Xs1, ul[p_], lS[5 + p_]);               // sum Xs_{t+1} u_t   (:190)
+                    lS[5 + PP + p_] = fma(ul[p_], Xs, lS[5 + PP + p_]);      // sum u_t Xs_t       (:191)
+                }
+                Xl = Xl1; Vl = Vl1; c = c1; Xs = Xs1;
+            }
+            if constexpr (LDSR_LEAD_CLOSED_VAR) {
+                // sum of Vp over the lane's steps from its entry value V_e:  Vp_j = A^(2j) V_e + Q (1 + .. + A^(2(j-1)))
+                if (l_closed) {
+                    lS[1] = fma(l_V, l_geo, Q * l_geo2);
+                } else {
+                    double vv = l_V;
+                    for (int j = 0; j < nj; j++) { lS[1] += vv; vv = fma(A2, vv, Q); }
+                }
+            }
+        }
         // ------------------------------------------------ one reduction per half, M-step, stop rule
         Sums<PP, QQ> S;
         {
             constexpr int NB = 5 + (DENSE ? 0 : 1);
             constexpr int NT = NB + QQ + 2 * PP;                     // the sweeps' sums
-            constexpr int NR = NT + (LEAD && !LSPLIT ? 7 + 4 * PP : 0);   // + the lead's (unless reduced already)
+            constexpr int NR = NT + (LEAD ? NLS : 0);                // + the lead's
             static_assert(NR <= 3 * LPC, "reduction gather handles three slots per lane");
             double red[NR];
-            if constexpr (LEAD && !LSPLIT) {
+            if constexpr (LEAD) {
 #pragma unroll
-                for (int i = 0; i < 7 + 4 * PP; i++) red[NT + i] = lS[i];
+                for (int i = 0; i < NLS; i++) red[NT + i] = lS[i];
             }
             red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
             if (!DENSE) red[5] = aSxx;
@@ -1155,21 +1159,15 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             const double termLast = shfl_d(tLv, hbase | lastLane);
             if constexpr (STEADY) { red[1] += addTx1x; red[2] += addPall; }
             if constexpr (LEAD) {
-                // (delta, eps) at the tail's first step close the lead's sums; mu1 / V1 come from t = 0
+                // eps = Vs - Vp at the tail's first step closes the lead's variance sums; mu1 / V1 come from t = 0
                 const double dlt = S.X0 - x_t1, eps = S.V0 - v_t1;
-                const double d2e = fma(dlt, dlt, eps);
-                if constexpr (LSPLIT) {
-#pragma unroll
-                    for (int i = 0; i < NLS; i++)
-                        lS[i] = shfl_d(red_slot(i, NLS, LPC) == 0 ? lt0 : lt1, hbase | red_home(i, NLS, LPC));
-                }
-                const double *l = LSPLIT ? lS : red + NT;
-                red[2] += (l[0] + l[1]) + fma(2.0 * dlt, l[2], d2e * l[3]);                 // sum Xs^2 + Vs
-                red[1] += l[4] + fma(dlt, l[5], fma(d2e, l[6], A * l[1]));                  // sum Xs' Xs + Vs' J
+                const double *l = red + NT;
+                red[2] += (l[0] + l[1]) + eps * l[2];                                       // sum Xs^2 + Vs
+                red[1] += l[3] + fma(eps, l[4], A * l[1]);                                  // sum Xs' Xs + Vs' J
 #pragma unroll
                 for (int p_ = 0; p_ < PP; p_++) {
-                    red[NB + QQ + p_] += fma(dlt, l[7 + PP + p_], l[7 + p_]);               // Tx1u
-                    red[NB + QQ + PP + p_] += fma(dlt, l[7 + 3 * PP + p_], l[7 + 2 * PP + p_]);   // Tux
+                    red[NB + QQ + p_] += l[5 + p_];                                         // Tx1u
+                    red[NB + QQ + PP + p_] += l[5 + PP + p_];                               // Tux
                 }
                 S.X0 = fma(c_first, dlt, th.mu1);
                 S.V0 = fma(c_first * c_first, eps, th.V1);

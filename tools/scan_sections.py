@@ -75,5 +75,28 @@ def run_pair(T=1024, p=1, q=2, cells=4096, niter=100):
         print(f"    {names[k]:28s} {med[k]:8.0f}  {100 * med[k] / tot:5.1f} %")
 
 
+def run_lead(T, p, q, cells, lead, niter=100):
+    """A paleo-type launch through AUTO (closed-form lead + sweeps of the tail): slot 0 = iteration
+    constants + the lead's two passes, slot 6 = the generic sweeps of the tail."""
+    rng = np.random.default_rng(4)
+    u = rng.standard_normal((p, T))
+    v = rng.standard_normal((q, T))
+    x = np.zeros(T)
+    for t in range(1, T):
+        x[t] = 0.8 * x[t - 1] + 0.3 * u[0, t - 1] + 0.3 * rng.standard_normal()
+    y = x + 0.4 * v[0] + 0.3 * rng.standard_normal(T)
+    y[:lead] = np.nan
+    th0 = api.make_init_packed(p, q, cells, seed=5)
+    r = api.em_batch(y[None, :], u, v, th0, niter=niter, tol=0.0, return_liks=True)
+    tk = r["liks"][:, :10] / niter
+    med = np.mean(tk, axis=0)
+    tot = med[:9].sum()
+    print(f"LEAD launch T={T} p={p} q={q} cells={cells} lead={lead}: {tot:8.0f} cycles / iteration, clock {100.0 * tot / med[9]:.0f} MHz")
+    for k, nme in ((7, "M-step+stop+loop"), (0, "constants + lead passes"), (6, "sweeps of the tail"), (8, "reduce+lik")):
+        print(f"    {nme:28s} {med[k]:8.0f}  {100 * med[k] / tot:5.1f} %")
+
+
 if __name__ == "__main__" and os.environ.get("SECTIONS_PAIR"):
     run_pair()
+    run_lead(2000, 1, 4, 10240, 1800)
+    run_lead(813, 1, 3, 24576, 733)
