@@ -211,6 +211,9 @@ __device__ __forceinline__ double dpp1(double src) {
 #ifndef LDSR_RED_DPP
 #define LDSR_RED_DPP 1
 #endif
+#ifndef LDSR_SCAN_HI_BASE      // LDS images beyond 64 KiB: a second base register for the far half
+#define LDSR_SCAN_HI_BASE 1
+#endif
 template <int D>
 __device__ __forceinline__ int xor_dpp_w(int v) {
     static_assert(D == 1 || D == 2 || D == 4 || D == 8, "row-local distances only");
@@ -480,12 +483,21 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     // travels in the scalar soffset operand (plain global loads made the compiler keep a 64-bit
     // address pair per 4 KiB window and spill ~400 VGPRs).
     constexpr int KP = scan_pairs(PP, QQ);
+    constexpr bool BIGIMG = !GIMG && LDSR_SCAN_HI_BASE && (long)scan_image_doubles(L, W, PP, QQ) * 8 > 65536;
+    int hi_pairs = 4096;       // (in 16-byte pairs, so that the far base keeps the alignment ds_read_b128 needs)
+    if constexpr (BIGIMG) asm volatile("" : "+v"(hi_pairs));
+    const double *ys_hi = ys + 2 * hi_pairs;
     auto val = [&](int j, int i) -> double {
         if constexpr (GIMG) {
             const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, vl * 16, (((j * KP + (i >> 1)) * NL) * 2 + (i & 1)) * 8, 0);
             return __hiloint2double((int)w.y, (int)w.x);
         } else {
-            return ys[((j * KP + (i >> 1)) * NL + vl) * 2 + (i & 1)];
+            // Images beyond 64 KiB: a ds_read's immediate offset has 16 bits, and the compiler formed the
+            // address of every far element with its own v_add_u32 (80 per EM iteration at (4,8), L = 16).
+            // A second base 64 KiB up, opaque to the compiler, serves the far half with immediates again.
+            const int e = (j * KP + (i >> 1)) * NL * 2 + (i & 1);
+            if (BIGIMG && e >= 8192) return ys_hi[e - 8192 + vl * 2];
+            return ys[e + vl * 2];
         }
     };
     auto Yat = [&](int j) { return val(j, 0); };
