@@ -128,14 +128,16 @@ def load_pmc(workload, mask, kernel, niter, tol):
             entries = json.load(f).get("entries", [])
     except (OSError, ValueError):
         return None, None
-    best = None
-    for e in entries:
+    # (several rounds may hold an entry for the same workload and kernel name: the latest round counts)
+    best = exact = None
+    for e in sorted(entries, key=lambda e_: str(e_.get("round", "")), reverse=True):
         if e.get("workload") != workload or e.get("mask", "dense") != mask:
             continue
-        exact = (e.get("kernel") == kernel and e.get("niter") == niter and e.get("tol") == tol)
-        if exact:
-            return e, False
+        if e.get("kernel") == kernel and e.get("niter") == niter and e.get("tol") == tol:
+            exact = exact or e
         best = best or e
+    if exact:
+        return exact, False
     return (best, True) if best else (None, None)
 
 
