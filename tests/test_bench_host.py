@@ -44,7 +44,7 @@ def test_pmc_summary_is_only_used_for_the_kernel_it_was_measured_on():
     import json
     import bench
     entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["entries"]
-    e = [x for x in entries if x["workload"] == "cfg2"][0]
+    e = sorted([x for x in entries if x["workload"] == "cfg2"], key=lambda x: x["round"])[-1]   # the latest round's
     got, stale = bench.load_pmc("cfg2", "dense", e["kernel"], e["niter"], e["tol"])
     assert got is e or got == e
     assert stale is False
@@ -73,3 +73,25 @@ def test_plain_multi_gpu_invocation_spawns_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_pmc_entry_of_the_latest_round_counts():
+    """bench.py quotes counter-measured fields (traffic, issue_frac, fp64_executed_frac) from the committed
+    rocprofv3 passes of the SAME kernel: when several rounds profiled a kernel of that name, the latest
+    round's entry -- not the first in the file -- and every committed bench line names the passes of
+    its own round."""
+    import json
+    import os
+    import bench
+    e, stale = bench.load_pmc("cfg2", "dense", "em_pair_kernel<1, 2, 32, 32, false, false>", 100, 0.0)
+    assert e is not None and stale is False
+    rounds = sorted({x["round"] for x in json.load(open(os.path.join(bench.ROOT, "profiles", "pmc_summary.json")))["entries"]
+                     if x.get("workload") == "cfg2"})
+    assert e["round"] == rounds[-1]
+    e2, stale2 = bench.load_pmc("cfg2", "dense", "some_other_kernel", 100, 0.0)
+    assert e2 is not None and stale2 is True and e2["round"] == rounds[-1]
+    for w in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        line = json.loads(open(os.path.join(bench.ROOT, "profiles", "%s_%s_bench.json" % (rounds[-1], w))).read().strip().splitlines()[-1])
+        src = line["roofline"].get("pmc_source") or []
+        assert src and all(("/%s_" % rounds[-1]) in s_ for s_ in src), (w, src)
+        assert line["roofline"]["pmc_stale"] is False and line["verified"]["ok"] is True
