@@ -342,8 +342,8 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_DENSE_F1_POW_MAXP   // widest padded inputs that take that form
 #define LDSR_DENSE_F1_POW_MAXP 4
 #endif
-#ifndef LDSR_DENSE_F1_POW_MAXQ
-#define LDSR_DENSE_F1_POW_MAXQ 4
+#ifndef LDSR_DENSE_F1_POW_MAXQ   // (8 since round 3: with the far LDS base the reversed read order no longer costs
+#define LDSR_DENSE_F1_POW_MAXQ 8  //  more than the flops save -- same box (4,8) -0.9 %, (2,8) -2.3 %, (1,8) -0.9 %)
 #endif
 #ifndef LDSR_GIMG_PREFETCH   // the same pipeline for the global image (same-box A/B: 2-5 % slower -- off)
 #define LDSR_GIMG_PREFETCH 0
@@ -627,8 +627,9 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             // per-step recursion.  Composing from the chunk's last step towards its first,
             //   (a, b, c) <- (a, b, c) * S_j = (a alpha + b C2R + c s20_j,  a Q + b + c bu_j,  c A),
             // touches nothing but the row: 11 flops per step instead of 18.  Same-box A/B: +2 % at
-            // (1,2), +1.5 % at (1,4) and (4,4), but -6 % at (1,8) and -1 % at (4,8) (eight-row
-            // inputs: the reversed read order costs more than the flops save), hence PP, QQ <= 4.
+            // (1,2), +1.5 % at (1,4) and (4,4); round 2 measured -6 % at (1,8) and -1 % at (4,8) (eight-row
+            // inputs: the reversed read order cost more than the flops saved) and kept QQ <= 4; with the
+            // far LDS base of round 3 it is +1..2 % there too: PP <= 4, QQ <= 8.
             double p00 = alpha, p01 = Q, p10 = C2R, p11 = 1.0;      // running square Bm^(2^bit)
             double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0;      // Bm^(L-1)
             bool have = false;
