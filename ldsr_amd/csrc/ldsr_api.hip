@@ -522,6 +522,25 @@ static bool pair_pays_with_early_stopping(int T, int PP, int QQ) {
     return T <= 416 && em_pair_waves_per_block(T, PP, QQ, 32, 0) == 4;
 }
 
+// does the LEAD form at lp lanes per cell fit a CU's LDS: the tail's image, the strips and the lead's u_t
+static bool lead_fits(int T, int tail, int PP, int QQ, int lp) {
+    const bool wide = PP > 4 || QQ > 4;
+    int Lc = 0;
+    long img = 0;
+    em_pair_layout(tail, PP, QQ, lp, &Lc, &img, true);
+    if (!img) return false;
+    const size_t lds = ((size_t)img + (wide ? 4 : 8) * (size_t)pair_strip_doubles(Lc) +
+                        (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
+    return lds <= 160 * 1024;
+}
+// four cells per wave for the tail of a lead: narrow inputs, tails of <= 256 steps (p = 3, 4 since the
+// lead's second pass sums 5 + 2 p values instead of 7 + 4 p: they fit the 16-lane reduction now)
+static bool lead_quad(int T, int tail, int PP, int QQ) {
+    return PP <= 4 && QQ <= 4 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16, true) && lead_fits(T, tail, PP, QQ, 16);
+}
+
+static bool lead_short34(int T, int tail, int PP) { return PP > 2 && T - tail < 512; }
+
 static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     if (!pair_enabled() || !lead_enabled() || lead_steps < 192 || PP > 8 || QQ > 8) return 0;
     const bool wide = PP > 4 || QQ > 4;     // (two cells per wave, LEAD form only: kernels_scan.hip pair_plan)
@@ -533,19 +552,12 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     // series the four-cells-per-wave kernel over all T steps is quicker (tools/auto_regret.py, same
     // box: T = 260 (4,4) 20 000 cells 1.86 ms against 1.29, to convergence 11.4 against 7.0; the Nakhon
     // Phanom shape, T = 813 with a lead of 733 steps, keeps it: 3.29 -> 2.50 ms)
-    if (PP > 2 && T - tail < 512) return 0;
-    // the lead's u_t live in LDS behind the tail's image and the eight strips
-    auto fits = [&](int lp) {
-        int Lc = 0;
-        long img = 0;
-        em_pair_layout(tail, PP, QQ, lp, &Lc, &img, true);
-        if (!img) return false;
-        const size_t lds = ((size_t)img + (wide ? 4 : 8) * (size_t)pair_strip_doubles(Lc) +
-                            (size_t)pair_lead_doubles(T - tail, lp, PP)) * sizeof(double);
-        return lds <= 160 * 1024;
-    };
-    // (p = 3, 4 and tails beyond 256 steps: two cells per wave only)
-    return ((PP > 2 || wide || tail > 256 || fits(16)) && fits(32)) ? tail : 0;
+    // (with four cells per wave -- p = 3, 4 since round 3, launches of >= 3/4 of a round -- the lead pays on
+    // short series too: the caller checks lead_short34() before it falls back to two cells per wave)
+    if (PP > 2 && T - tail < 512 && !lead_quad(T, tail, PP, QQ)) return 0;
+    // the lead's u_t live in LDS behind the tail's image and the strips
+    (void)wide;
+    return lead_fits(T, tail, PP, QQ, 32) ? tail : 0;
 }
 
 static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len,
@@ -558,7 +570,7 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
     const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
     const int tail = algo == LDSR_ALGO_AUTO ? lead_tail(T, PP, QQ, lead_steps) : 0;
     if (!tail) return em_plan_impl(T, p, q, niter, tol, algo, buf, len, lead_steps < 0);
-    const int lpc = (PP <= 2 && QQ <= 4 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16)) ? 16 : 32;
+    const int lpc = lead_quad(T, tail, PP, QQ) ? 16 : 32;
     if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0 || PP > 4 || QQ > 4, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
 }
@@ -675,6 +687,10 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // ms: T = 2000 (1,4) 3.61 -> 2.44, (3,5) 17.1 -> 3.96, T = 4000 (2,2) 6.30 -> 4.95; at T = 1100..1300
         // it is a toss-up (1.40 -> 1.48, 1.81 -> 2.07, 2.17 -> 1.78)
         if (lead_form && T >= 1536) return true;
+        // (four cells per wave with p = 3, 4 -- possible since the lead's second pass sums 5 + 2 p values --
+        // pay from 3/4 of a device-filling round: same box, two -> four cells per wave in ms, T = 813 (3,3)
+        // 8192 cells 2.33 -> 1.55, 2048 cells 0.82 -> 0.98; T = 2000 (3,4) 4096 cells 2.25 -> 2.64)
+        if (lead_form && lp == 16 && PP > 2) return wgs * 4 >= 3 * cus;
         if (lead_form && (tol == 0.0 || lead_hint >= 1024))
             return wgs * (lp == 16 ? 16 : 8) >= 3 * cus;
         return wgs * 8 >= 7 * cus;
@@ -687,8 +703,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (was_auto && algo != LDSR_ALGO_SERIAL) {
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
-            if (PP <= 2 && QQ <= 4 && tail <= 256 && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
-            else if (fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
+            if (lead_quad(T, tail, PP, QQ) && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
+            else if (!lead_short34(T, tail, PP) && fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }
     if (lead_force > 0 && (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD)) lead = lead_force;   // (a re-run of part of a batch)

@@ -72,6 +72,8 @@ def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
     (1000, 1, 2, 1, 560, True, 0),         # tails of 257..512 steps: two cells per wave, chunks of <= 16 steps
     (2000, 2, 4, 2, 1500, False, 6),
     (1500, 3, 3, 1, 1100, True, 0),
+    (500, 3, 3, 2, 400, True, 4),          # p = 3 on a short series: four cells per wave (launches of >= 6144 cells)
+    (900, 4, 4, 1, 700, False, 0),
     # wide inputs (padded p or q = 8): the two-cells-per-wave LEAD form with the work-queue schedule
     (1024, 4, 8, 1, 816, False, 0),        # config 3's shape with the paleo mask
     (813, 7, 7, 2, 733, True, 3),          # the known-answer problem's width (p = q = 7) on the Nakhon Phanom length
@@ -118,7 +120,9 @@ def test_lead_plan_and_limits(eng):
     assert plan(1000, 1, 2, 900, 1e-5) == (4, "em_pair_kernel<1, 2, 7, 16, true, true>")
     assert plan(813, 1, 3, 723)[1] == "em_pair_kernel<1, 4, 6, 16, false, true>"           # config 5
     # no closed form: short leads, tails beyond 512 steps, wide u, explicit algorithms -- the ordinary plan
-    assert plan(813, 3, 3, 760)[1] == "em_pair_kernel<4, 4, 3, 32, false, true>"           # p = 3,4: two cells per wave
+    assert plan(813, 3, 3, 760) == (4, "em_pair_kernel<4, 4, 5, 16, false, true>")          # p = 3, 4: four cells per wave too
+    assert plan(500, 3, 3, 420)[1] == "em_pair_kernel<4, 4, 5, 16, false, true>"           # ... also on short series
+    assert plan(1500, 3, 3, 1100)[1] == "em_pair_kernel<4, 4, 13, 32, false, true>"        # tails beyond 256 steps: two
     assert plan(1000, 1, 2, 600)[1] == "em_pair_kernel<1, 2, 13, 32, false, true>"         # tail of 400 steps
     assert plan(2000, 1, 4, 1500, 1e-5) == (3, "em_pair_kernel<1, 4, 16, 32, true, true>")
     # wide inputs (padded p or q = 8): two cells per wave, work queue
