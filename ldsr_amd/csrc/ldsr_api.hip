@@ -536,7 +536,7 @@ static bool lead_fits(int T, int tail, int PP, int QQ, int lp) {
 // four cells per wave for the tail of a lead: narrow inputs, tails of <= 256 steps (p = 3, 4 since the
 // lead's second pass sums 5 + 2 p values instead of 7 + 4 p: they fit the 16-lane reduction now)
 static bool lead_quad(int T, int tail, int PP, int QQ) {
-    return PP <= 4 && QQ <= 4 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16, true) && lead_fits(T, tail, PP, QQ, 16);
+    return PP <= 8 && QQ <= 8 && tail <= 256 && em_pair_supported(tail, PP, QQ, 16, true) && lead_fits(T, tail, PP, QQ, 16);
 }
 
 static bool lead_short34(int T, int tail, int PP) { return PP > 2 && T - tail < 512; }
@@ -690,7 +690,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // (four cells per wave with p = 3, 4 -- possible since the lead's second pass sums 5 + 2 p values --
         // pay from 3/4 of a device-filling round: same box, two -> four cells per wave in ms, T = 813 (3,3)
         // 8192 cells 2.33 -> 1.55, 2048 cells 0.82 -> 0.98; T = 2000 (3,4) 4096 cells 2.25 -> 2.64)
-        if (lead_form && lp == 16 && PP > 2) return wgs * 4 >= 3 * cus;
+        if (lead_form && lp == 16 && (PP > 2 || QQ > 4)) return wgs * 4 >= 3 * cus;
         if (lead_form && (tol == 0.0 || lead_hint >= 1024))
             return wgs * (lp == 16 ? 16 : 8) >= 3 * cus;
         return wgs * 8 >= 7 * cus;
@@ -740,7 +740,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         return fail(LDSR_EINVAL, "LDSR_ALGO_SCAN needs T <= 8192 and p, q <= 8 (and T >= L (L - 1) for its chunk length)");
     if (algo == LDSR_ALGO_PAIR && !em_pair_supported(Te, PP, QQ, 32, lead > 0))
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
-    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16))
+    if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16, lead > 0))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
     // Wide inputs (padded p or q = 8), every series fully observed: the scan kernel's plan and image,
     // the pair family's body with its steady-state sweeps, ONE cell per wave (LDSR_WAVE64=0: off)

@@ -79,7 +79,8 @@ def _run_and_check(eng, Y, U, V, off, th0, niter, tol, what):
     (813, 7, 7, 2, 733, True, 3),          # the known-answer problem's width (p = q = 7) on the Nakhon Phanom length
     (1000, 1, 8, 1, 900, False, 0),
     (1200, 6, 2, 1, 1000, False, 0),
-    (2000, 3, 5, 1, 1500, True, 0),        # tail of 500 steps
+    (2000, 3, 5, 1, 1500, True, 0),        # tail of 500 steps: two cells per wave
+    (900, 2, 7, 2, 740, True, 5),          # four cells per wave (8192 cells)
 ])
 def test_lead_matches_oracle(eng, T, p, q, S, lead, holes, stagger):
     Y, U, V, off, th0 = _grid(T, p, q, S, lead, 8192 // S, 60 + T, holes, stagger)
@@ -125,9 +126,10 @@ def test_lead_plan_and_limits(eng):
     assert plan(1500, 3, 3, 1100)[1] == "em_pair_kernel<4, 4, 13, 32, false, true>"        # tails beyond 256 steps: two
     assert plan(1000, 1, 2, 600)[1] == "em_pair_kernel<1, 2, 13, 32, false, true>"         # tail of 400 steps
     assert plan(2000, 1, 4, 1500, 1e-5) == (3, "em_pair_kernel<1, 4, 16, 32, true, true>")
-    # wide inputs (padded p or q = 8): two cells per wave, work queue
-    assert plan(1000, 5, 2, 900) == (3, "em_pair_kernel<8, 2, 4, 32, true, true>")
-    assert plan(1024, 4, 8, 816)[1] == "em_pair_kernel<4, 8, 7, 32, true, true>"             # config 3's shape, paleo mask
+    # wide inputs (padded p or q = 8): work queue; four cells per wave for tails of <= 256 steps (not p = q = 8)
+    assert plan(1000, 5, 2, 900) == (4, "em_pair_kernel<8, 2, 7, 16, true, true>")
+    assert plan(1024, 4, 8, 816)[1] == "em_pair_kernel<4, 8, 13, 16, true, true>"            # config 3's shape, paleo mask
+    assert plan(2000, 3, 5, 1500) == (3, "em_pair_kernel<4, 8, 16, 32, true, true>")        # tail of 500 steps: two
     assert plan(813, 7, 7, 733, 1e-5)[1] == "em_pair_kernel<8, 8, 3, 32, true, true>"
     for args in ((1000, 1, 2, 100), (1000, 1, 2, 480), (1000, 9, 2, 900), (1000, 1, 12, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
