@@ -137,10 +137,11 @@ def test_lead_plan_and_limits(eng):
     assert plan(1000, 1, 2, 900, 0.0, 3)[1] == "em_pair_kernel<1, 2, 32, 32, false, false>"
 
 
-def test_restart_grid_with_a_lead(eng, monkeypatch):
+@pytest.mark.parametrize("p,q", [(1, 2), (3, 3), (5, 6)])      # four cells per wave: narrow, p = 3, wide
+def test_restart_grid_with_a_lead(eng, monkeypatch, p, q):
     """ldsr_em_restart_grid on a paleo-type fold grid: per-fold winners, traces and fits agree with
     the batch entry + host logic, also when the winners are re-run alone for their traces."""
-    Y, U, V, off, th0 = _grid(1000, 1, 2, 2, 880, 4096, 7, holes=True)
+    Y, U, V, off, th0 = _grid(1000, p, q, 2, 880, 4096, 7, holes=True)
     u, v = U[0].T.copy(), V[0].T.copy()          # shared inputs, one mask per fold (cvLDS)
     Y[1, 950:960] = np.nan
     a = eng.em_restart_grid(Y, u, v, th0, cell_offsets=off, niter=60, tol=1e-5)
@@ -148,7 +149,7 @@ def test_restart_grid_with_a_lead(eng, monkeypatch):
     ref = eng.em_batch(Y, u, v, th0, cell_offsets=off, niter=60, tol=1e-5, return_liks=True)
     for f in range(2):
         lo, hi = off[f], off[f + 1]
-        w = lo + eng.select_restart(ref["lik"][lo:hi], ref["theta"][lo:hi], 1, 2)
+        w = lo + eng.select_restart(ref["lik"][lo:hi], ref["theta"][lo:hi], p, q)
         assert int(a["winner"][f]) == w
         assert np.array_equal(a["theta"][f], ref["theta"][w]) and a["lik"][f] == ref["lik"][w]
         k = ref["n_iter"][w]
