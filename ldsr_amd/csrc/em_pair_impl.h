@@ -1128,7 +1128,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             constexpr int NB = 5 + (DENSE ? 0 : 1);
             constexpr int NT = NB + QQ + 2 * PP;                     // the sweeps' sums
             constexpr int NR = NT + (LEAD ? NLS : 0);                // + the lead's
-            static_assert(NR <= 3 * LPC, "reduction gather handles three slots per lane");
+            constexpr int NSL = (NR + LPC - 1) / LPC;                // live slots per lane after the halving rounds
+            static_assert(NSL <= 4, "reduction gather: at most four slots per lane");
             double red[NR];
             if constexpr (LEAD) {
 #pragma unroll
@@ -1146,13 +1147,12 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             {
                 // (more values than lanes -- 17 or 18 sums on the 16 lanes of a quad cell -- leave two
                 // live slots per lane)
-                // (... and the 30 + 39 sums of p = q = 8 with a lead three on 32 lanes)
-                const double t0 = red[0], t1 = red[1], t2 = red[NR > 2 * LPC ? 2 : 0];
+                // (... and the 30 + 21 sums of p = q = 8 with a lead four on 16 lanes)
+                double tt[NSL];
 #pragma unroll
-                for (int i = 0; i < NR; i++) {
-                    const int sl = red_slot(i, NR, LPC);
-                    red[i] = shfl_d(sl == 0 ? t0 : sl == 1 ? t1 : t2, hbase | red_home(i, NR, LPC));
-                }
+                for (int k_ = 0; k_ < NSL; k_++) tt[k_] = red[k_];
+#pragma unroll
+                for (int i = 0; i < NR; i++) red[i] = shfl_d(tt[red_slot(i, NR, LPC)], hbase | red_home(i, NR, LPC));
             }
             S.X0 = shfl_d(X0v, hbase);               // :218
             S.V0 = shfl_d(V0v, hbase);               // :219

@@ -126,7 +126,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
     // registers of two waves per SIMD at q = 8; the lead itself never touches v_t).
     const bool wide = PP > 4 || QQ > 4;
     if ((lpc != 32 && lpc != 16) || PP > 8 || QQ > 8 || T <= 64) return p;
-    if (wide && !(lead_form && ((lpc == 32 && T <= 512) || (lpc == 16 && T <= 256 && !(PP == 8 && QQ == 8))))) return p;   // ((8,8) at four cells per wave: 51 sums on 16 lanes)
+    if (wide && !(lead_form && ((lpc == 32 && T <= 512) || (lpc == 16 && T <= 256)))) return p;
     // every chunk length from 3 to 32: the shortest one wastes no lanes (four cells per wave: from 5)
     // (lanes 0 .. rp-1 own L steps, the others L-1: needs 1 <= rp <= nl)
     for (int L = (lpc == 16 ? 5 : 3); L <= 32; L++) {

@@ -557,7 +557,9 @@ static int lead_tail(int T, int PP, int QQ, int lead_steps) {
     if (PP > 2 && T - tail < 512 && !lead_quad(T, tail, PP, QQ)) return 0;
     // the lead's u_t live in LDS behind the tail's image and the strips
     (void)wide;
-    return lead_fits(T, tail, PP, QQ, 32) ? tail : 0;
+    if (lead_quad(T, tail, PP, QQ)) return tail;
+    // (padded p = 8 up to T = 1024: four cells per wave or the scan kernel, see em_batch_device_impl)
+    return ((PP < 8 || T > 1024) && lead_fits(T, tail, PP, QQ, 32)) ? tail : 0;
 }
 
 static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, char *buf, size_t len,
@@ -686,11 +688,13 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // memory): there the lead pays whatever the launch size -- 50 lone cells, niter = 200, scan -> LEAD in
         // ms: T = 2000 (1,4) 3.61 -> 2.44, (3,5) 17.1 -> 3.96, T = 4000 (2,2) 6.30 -> 4.95; at T = 1100..1300
         // it is a toss-up (1.40 -> 1.48, 1.81 -> 2.07, 2.17 -> 1.78)
+        // (four cells per wave with p = 3, 4 or wide inputs -- possible since the lead's second pass sums
+        // 5 + 2 p values -- pay from 3072 cells, with leads of 1024 steps and more from 6144: same box, two ->
+        // four cells per wave in ms, T = 813 (3,3) 8192 cells 2.33 -> 1.55, 4096 1.24 -> 1.06, 3072 1.21 -> 1.03,
+        // 2048 0.82 -> 0.98; (4,8) T = 1024 3072 cells 1.52 -> 1.26, 2048 1.06 -> 1.22; T = 2000 (3,4) 4096
+        // cells 2.25 -> 2.64, 6144 4.33 -> 2.73)
+        if (lead_form && lp == 16 && (PP > 2 || QQ > 4)) return wgs * (lead_hint >= 1024 ? 4 : 8) >= 3 * cus;
         if (lead_form && T >= 1536) return true;
-        // (four cells per wave with p = 3, 4 -- possible since the lead's second pass sums 5 + 2 p values --
-        // pay from 3/4 of a device-filling round: same box, two -> four cells per wave in ms, T = 813 (3,3)
-        // 8192 cells 2.33 -> 1.55, 2048 cells 0.82 -> 0.98; T = 2000 (3,4) 4096 cells 2.25 -> 2.64)
-        if (lead_form && lp == 16 && (PP > 2 || QQ > 4)) return wgs * 4 >= 3 * cus;
         if (lead_form && (tol == 0.0 || lead_hint >= 1024))
             return wgs * (lp == 16 ? 16 : 8) >= 3 * cus;
         return wgs * 8 >= 7 * cus;
@@ -704,7 +708,10 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         const int tail = lead_tail(T, PP, QQ, lead_hint);
         if (tail) {
             if (lead_quad(T, tail, PP, QQ) && fills(tail, 16, true)) { lead = T - tail; lpc = 16; algo = LDSR_ALGO_QUAD; }
-            else if (!lead_short34(T, tail, PP) && fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
+            // (two cells per wave with padded p = 8 run ONE four-wave workgroup per CU and lose to the scan kernel:
+            // T = 813 (7,7) 2048 cells 1.76 against 1.40 ms, 4096 cells 3.03 against 2.66, four per wave 1.89)
+            // (beyond T = 1024 the scan kernel's chunks are long and they win again)
+            else if ((PP < 8 || T > 1024) && !lead_short34(T, tail, PP) && fills(tail, 32, true)) { lead = T - tail; lpc = 32; algo = LDSR_ALGO_PAIR; }
         }
     }
     if (lead_force > 0 && (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD)) lead = lead_force;   // (a re-run of part of a batch)

@@ -130,7 +130,9 @@ def test_lead_plan_and_limits(eng):
     assert plan(1000, 5, 2, 900) == (4, "em_pair_kernel<8, 2, 7, 16, true, true>")
     assert plan(1024, 4, 8, 816)[1] == "em_pair_kernel<4, 8, 13, 16, true, true>"            # config 3's shape, paleo mask
     assert plan(2000, 3, 5, 1500) == (3, "em_pair_kernel<4, 8, 16, 32, true, true>")        # tail of 500 steps: two
-    assert plan(813, 7, 7, 733, 1e-5)[1] == "em_pair_kernel<8, 8, 3, 32, true, true>"
+    assert plan(813, 7, 7, 733, 1e-5) == (4, "em_pair_kernel<8, 8, 5, 16, true, true>")     # padded p = 8: four per wave or none
+    assert plan(1000, 7, 2, 600)[1].startswith("em_scan_kernel")                           # ... tail of 400 steps: scan kernel
+    assert plan(1500, 7, 2, 1100)[1] == "em_pair_kernel<8, 2, 13, 32, true, true>"         # ... beyond T = 1024: two per wave
     for args in ((1000, 1, 2, 100), (1000, 1, 2, 480), (1000, 9, 2, 900), (1000, 1, 12, 900)):
         assert not plan(*args)[1].endswith(", true>"), args
     assert plan(1000, 1, 2, 900, 0.0, 2)[1].startswith("em_scan_kernel")
