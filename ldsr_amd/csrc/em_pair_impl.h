@@ -1122,6 +1122,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                 }
             }
         }
+        SCAN_TICK(5)       // (LEAD: the second pass)
         // ------------------------------------------------ one reduction per half, M-step, stop rule
         Sums<PP, QQ> S;
         {

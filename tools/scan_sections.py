@@ -77,7 +77,8 @@ def run_pair(T=1024, p=1, q=2, cells=4096, niter=100):
 
 def run_lead(T, p, q, cells, lead, niter=100):
     """A paleo-type launch through AUTO (closed-form lead + sweeps of the tail): slot 0 = iteration
-    constants + the lead's two passes, slot 6 = the generic sweeps of the tail."""
+    constants + the lead's first pass, slot 6 = the generic sweeps of the tail, slot 5 = the lead's
+    second pass (behind the sweeps)."""
     rng = np.random.default_rng(4)
     u = rng.standard_normal((p, T))
     v = rng.standard_normal((q, T))
@@ -92,7 +93,8 @@ def run_lead(T, p, q, cells, lead, niter=100):
     med = np.mean(tk, axis=0)
     tot = med[:9].sum()
     print(f"LEAD launch T={T} p={p} q={q} cells={cells} lead={lead}: {tot:8.0f} cycles / iteration, clock {100.0 * tot / med[9]:.0f} MHz")
-    for k, nme in ((7, "M-step+stop+loop"), (0, "constants + lead passes"), (6, "sweeps of the tail"), (8, "reduce+lik")):
+    for k, nme in ((7, "M-step+stop+loop"), (0, "constants + first lead pass"), (6, "sweeps of the tail"),
+                   (5, "second lead pass"), (8, "reduce+lik")):
         print(f"    {nme:28s} {med[k]:8.0f}  {100 * med[k] / tot:5.1f} %")
 
 
