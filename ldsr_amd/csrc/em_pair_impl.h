@@ -32,7 +32,7 @@
 // lanes per cell LPC = 32 (two cells per wave, T <= 1024) or 16 (FOUR cells per wave, one per DPP
 // row, T <= 512): the series image has LPC virtual lanes
 __host__ __device__ constexpr long pair_image_doubles(int L, int PP, int QQ, int LPC = 32) {
-    return (long)LPC * L * 2 * scan_pairs(PP, QQ);
+    return img_doubles(L, LPC, PP, QQ);
 }
 // LDS strip of one wave: h_t of steps 0 .. L-2 for 64 lanes (the predicated step L-1 keeps its
 // h in a register)
@@ -59,41 +59,18 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY_SBMASK     // what may still cross the per-step scheduling barriers (0x2 VALU | 0x4 SALU)
 #define LDSR_STEADY_SBMASK 0x6
 #endif
-#ifndef LDSR_W64_BU_RECOMPUTE   // one cell per wave: F2 re-forms B u_t from the image instead of keeping it
-#define LDSR_W64_BU_RECOMPUTE 1
-#endif
-#ifndef LDSR_W64_UNIFORM
-#define LDSR_W64_UNIFORM 1
-#endif
 #ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
 #define LDSR_STEADY_MIN_L 24
 #endif
-// steps of the transient block: two cells per wave L-1 (lane 0's chunk), one cell per wave the
-// first 64 / L chunks less one step (63 lanes hold a step each, the 64th is the template)
-__host__ __device__ constexpr int pair_steady_ntr(int L, int LPC) { return (LPC == 64 ? (64 / L) * L : L) - 1; }
+// steps of the transient block: L-1 (the chunk of lane 0 without its predicated step)
+__host__ __device__ constexpr int pair_steady_ntr(int L, int LPC) { return L - 1; }
 __host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
     if (!LDSR_STEADY) return false;
-    if (LPC == 64)
-        return L <= 16 && pair_steady_ntr(L, LPC) >= LDSR_STEADY_MIN_L - 1 &&
-               (pair_image_doubles(L, PP, QQ, LPC) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
     return LPC == 32 && L >= LDSR_STEADY_MIN_L &&
            (pair_image_doubles(L, PP, QQ, LPC) + 8 * pair_strip_doubles(L) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
 }
 
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
-
-// LPC = 64: ONE cell per wave (wide inputs: padded p or q = 8, chunks of <= 16 steps).  The
-// per-step values that must survive from the forward to the backward sweep then fit the
-// registers (3 x 16 doubles), so there is no strip; the image is the scan kernel's
-// (em_scan_impl.h: same layout, 64 virtual lanes).
-// Built with `make WAVE64=1` only.  Measured on BASELINE config 3 (T = 1000, p = 4, q = 8, 8192
-// cells x 100 iterations, same box): scan kernel 4.09 ms; this member 4.80 ms with its fallback,
-// 3.91 ms if every cell were steady -- 1820 VALU instructions per unit of which only 1041 are fp64
-// (scan kernel: 2192 / 1465): at 64 lanes x 16 steps the per-iteration fixed work (transient block
-// of 63 steps, two more scans, 21-value reduction, the (4,8) M-step) and the SGPR spill traffic of
-// a wave-uniform theta eat what the steady sweeps save.  Kept because it is parity-tested
-// (BASELINE config 3 whole, niter = 1000, tol = 1e-5) and a starting point, not selected by AUTO.
-__host__ __device__ constexpr bool pair_hreg(int LPC) { return LPC == 64; }
 
 // Cross-row step of the reverse scans.  After the four row-shift rounds lane l holds the
 // composite (P, G, H) of lanes l .. end of its 16-lane row; every lane then applies the composite
@@ -108,19 +85,6 @@ __device__ __forceinline__ void rscan_cross(double &P, double &G, double &H, int
         const double Gs = row == 0 ? G1 : row == 2 ? G3 : 0.0;
         const double Hs = row == 0 ? H1 : row == 2 ? H3 : 0.0;
         const double Ps = row == 0 ? P1 : row == 2 ? P3 : 1.0;
-        G = fma(P, Gs, G);
-        H = fma(P * P, Hs, H);
-        P *= Ps;
-    } else if constexpr (LPC == 64) {
-        const double P3 = readlane_d(P, 48), G3 = readlane_d(G, 48), H3 = readlane_d(H, 48);
-        const double P2 = readlane_d(P, 32), G2 = readlane_d(G, 32), H2 = readlane_d(H, 32);
-        const double P1 = readlane_d(P, 16), G1 = readlane_d(G, 16), H1 = readlane_d(H, 16);
-        const double G23 = fma(P2, G3, G2), H23 = fma(P2 * P2, H3, H2), P23 = P2 * P3;      // rows 2, 3
-        const double G123 = fma(P1, G23, G1), H123 = fma(P1 * P1, H23, H1), P123 = P1 * P23;
-        const int row = lane >> 4;
-        const double Gs = row == 0 ? G123 : row == 1 ? G23 : row == 2 ? G3 : 0.0;
-        const double Hs = row == 0 ? H123 : row == 1 ? H23 : row == 2 ? H3 : 0.0;
-        const double Ps = row == 0 ? P123 : row == 1 ? P23 : row == 2 ? P3 : 1.0;
         G = fma(P, Gs, G);
         H = fma(P * P, Hs, H);
         P *= Ps;
@@ -144,11 +108,9 @@ template <int PP, int QQ, int L, int LPC, bool DENSE>
 __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> &th,
                                                     const double *ys, double *hs, unsigned obsmask,
                                                     int lane, int nl, int rp, double x_t1, double v_t1) {
-    constexpr int KP = scan_pairs(PP, QQ);
-    constexpr bool HREG = pair_hreg(LPC);        // h_t in registers (one cell per wave, L <= 16)
-    static_assert(!HREG || L <= 16, "one cell per wave: chunks of at most 16 steps");
+    constexpr int KV = img_values(PP, QQ);
     const int vl = lane & (LPC - 1);
-    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
+    auto val = [&](int j, int i) -> double { return ys[img_off(j, i, KV, LPC, L) + vl * 2]; };
     auto Yat = [&](int j) { return val(j, 0); };
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
@@ -170,7 +132,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
         for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
         return bu;
     };
-    double Jv[L], gv_[L], hv[HREG ? L : 1];
+    double Jv[L], gv_[L];
     double hlast = 0.0;      // h of the predicated step L-1
     double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
     int sneg = 0;
@@ -269,7 +231,6 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     prenorm(M);
     M = pmul(M, pdpp<DPP_ROW_SHR(8), 0xF>(M));
     if constexpr (LPC >= 32) M = pmul(M, pdpp<DPP_ROW_BCAST15, 0xA>(M));      // lane 15 -> row 1, lane 47 -> row 3
-    if constexpr (LPC == 64) { prenorm(M); M = pmul(M, pdpp<DPP_ROW_BCAST31, 0xC>(M)); }   // lane 31 -> rows 2, 3
     // exit state of this lane's chunk, then the entry state = exit state of the lane before
     // (lane 0 of each half: the cell's initial state)
     const double n_in = v_t1, d_in = 1.0, x_in = x_t1;      // (LEAD: the state at the tail's first step)
@@ -331,8 +292,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
             h = fin ? Vu : h;
         }
         Jv[j] = J; gv_[j] = g;
-        if constexpr (HREG) hv[j] = h;
-        else { if (j < L - 1) hs[j * 64] = h; else hlast = h; }
+        if (j < L - 1) hs[j * 64] = h; else hlast = h;
         G = fma(Pi, g, G);
         H = fma(Pi * Pi, h, H);
         Pi *= J;
@@ -375,9 +335,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     auto b2a = [&](int j) {
         const bool o = DENSE || ((obsmask >> j) & 1u);
         const double J = Jv[j];
-        double h;
-        if constexpr (HREG) h = hv[j];
-        else h = (j < L - 1) ? hs[j * 64] : hlast;
+        const double h = (j < L - 1) ? hs[j * 64] : hlast;
         aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
         const double Xs = fma(J, Xn, gv_[j]);       // :101
         const double Vs = fma(J * J, Vn, h);        // :102
@@ -425,44 +383,15 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
 #pragma unroll
     for (int p_ = 0; p_ < PP; p_++) { o.aTx1u[p_] = aTx1u[p_]; o.aTux[p_] = aTux[p_]; }
 }
-// The same as a real call: in the STEADY form of em_pair_body the generic sweeps are the rare
-// fallback (cells whose Riccati recursion has not converged within the transient block), and
-// inlined next to the steady sweeps their 244 registers made the allocator spill values that live
-// across the whole EM loop on the steady path too.
-template <int PP, int QQ, int L, int LPC, bool DENSE>
-__device__ __attribute__((noinline)) void pair_generic_sweeps_call(PairSweepOut<PP, QQ> &o, const Theta<PP, QQ> th,
-                                                                   const double *ys, double *hs, unsigned obsmask,
-                                                                   int lane, int nl, int rp, double x_t1, double v_t1) {
-    // (theta BY VALUE: handed over by reference, the caller's theta lived on its stack and was
-    // re-read from scratch at the top of every EM iteration, steady or not)
-    PairSweepOut<PP, QQ> t;
-    pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(t, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
-    o = t;
-}
-
-template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD, bool STEADY = false>
+template <int PP, int QQ, int L, int LPC, bool DENSE, bool QUEUE, bool LEAD>
 __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *ys, double *hs,
-                                             const double *lu, const double *tri, int s, int c0, int nc, int lane,
+                                             const double *lu, int s, int c0, int nc, int lane,
                                              int wave) {
     static_assert(!(LEAD && DENSE), "a lead of missing steps and a fully observed series exclude each other");
-    static_assert(!STEADY || (DENSE && LPC >= 32), "the steady sweeps: fully observed series, one or two cells per wave");
-    static_assert(!(LEAD && LPC == 64), "no closed-form lead for one cell per wave");
-    constexpr int KP = scan_pairs(PP, QQ);
-    static_assert(LPC == 64 || LPC == 32 || LPC == 16, "one, two or four cells per wave");
-    constexpr bool HREG = pair_hreg(LPC);
+    static_assert(LPC == 32 || LPC == 16, "two or four cells per wave");
     constexpr int CPW = 64 / LPC;                         // cells per wave
     // `half` = which cell of the wave this lane works for (the name dates from LPC = 32)
     const int half = lane / LPC, vl = lane & (LPC - 1), hbase = lane & ~(LPC - 1);
-    auto val = [&](int j, int i) -> double { return ys[((j * KP + (i >> 1)) * LPC + vl) * 2 + (i & 1)]; };
-    // all 2 KP values of step j of this lane (ds_read_b128 each pair)
-    auto ldw = [&](int j, double (&w)[2 * KP]) {
-#pragma unroll
-        for (int i = 0; i < 2 * KP; i++) w[i] = val(j, i);
-    };
-    // steady sweeps: steps the image is read ahead (a step is KP 16-byte pairs: wide inputs get a
-    // shorter ring) and the strip
-    constexpr int PF = KP <= 2 ? LDSR_STEADY_PF : (KP <= 4 ? 2 : 1);
-    constexpr int PF2 = LDSR_STEADY_PF2;
     // LEAD: the first `lead` steps of every series of the launch are unobserved and are handled in
     // closed form (below); the sweeps work on the tail [lead, T) only, all indices tail relative
     const int lead = LEAD ? prm.lead : 0;
@@ -498,24 +427,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     Theta<PP, QQ> th;
     load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
     white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
-    // one cell per wave: theta is wave-uniform by construction; say so to the compiler (SGPR residency)
-    auto make_uniform = [](Theta<PP, QQ> &t) {
-        t.A = uniform_d(t.A); t.C = uniform_d(t.C); t.Q = uniform_d(t.Q);
-        t.R = uniform_d(t.R); t.mu1 = uniform_d(t.mu1); t.V1 = uniform_d(t.V1);
-#pragma unroll
-        for (int k_ = 0; k_ < PP; k_++) t.B[k_] = uniform_d(t.B[k_]);
-#pragma unroll
-        for (int k_ = 0; k_ < QQ; k_++) t.D[k_] = uniform_d(t.D[k_]);
-    };
-    if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
-
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
-    double gv_[STEADY ? L : 1];   // steady sweeps: e_t, then g_t of this lane's steps
-    // ... and B u_t where there is no strip (one cell per wave) -- unless F2 re-forms it from the
-    // image (LDSR_W64_BU_RECOMPUTE: p products and ~p/2 LDS reads per step for 2 L registers)
-    constexpr bool BUREG = STEADY && HREG && !LDSR_W64_BU_RECOMPUTE;
-    double buv[BUREG ? L : 1];
     int wit = 0;             // wave-uniform iteration count (interrupt poll)
 #ifdef LDSR_SCAN_TIMING
     unsigned long long tick_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -658,7 +571,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 
         // ------------------------------------------------ outputs of the sweeps (either form)
         double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
-        double addPall = 0.0, addTx1x = 0.0;    // STEADY: closed-form variance sums of the steady region
         int sneg = 0;
         // (zeroed where a branch starts to accumulate, not here: as values defined at the top of the
         // iteration they held 2 (5 + q + 2p) registers through the forward sweeps -- 42 at p = 4, q = 8)
@@ -672,397 +584,21 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
         };
 
-        // ------------------------------------------------ STEADY: transient block and verdict
-        // With every y_t observed the variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t:
-        // src/EM.cpp:76,86,88,100) is the data-independent Riccati recursion, which reaches its
-        // fixed point geometrically -- within 15..25 steps for 99 % of the (cell, iteration) pairs
-        // of BASELINE config 2.  The first NTR = L-1 steps of the series (the chunk of lane 0 without
-        // its predicated step) are done ONE STEP PER LANE with the generic machinery (step matrix,
-        // 3x3 scan, the reference's expressions from the exact entry state); lane 31 is no
-        // transient step (NTR <= 31), its "entry state" is the state at t = NTR and what it
-        // evaluates there are the steady constants K, 1/Sigma, Vu, J, h.  Verdict, per CELL (a
-        // cell's arithmetic never depends on its wave partner): one more step leaves Vp unchanged
-        // to 2^-48 (and J^2 < 0.8, which a converged Riccati recursion implies unless V1 happens to be
-        // the fixed point itself: it lets the closed-form variance sums drop J^(2(T-NTR))).  Cells that pass run the steady sweeps below on t >= NTR: only the mean
-        // recursions (affine, constant multipliers), 20 fp64 operations per step where the generic
-        // sweeps take 50, no h_t strip, the variance sums in closed form.  Cells that fail (slow
-        // Riccati convergence: A near 1 with a small gain, mostly in the first EM iterations) take
-        // the generic sweeps for this iteration.
-        // One cell per wave (LPC = 64): the 63 other lanes make the transient block K0 = 64 / L chunks
-        // long; lanes 0 .. K0-2 then have no steady step, lane K0-1 its predicated step only.
-        constexpr int K0 = LPC == 64 ? 64 / L : 1;
-        constexpr int NTR = K0 * L - 1;
-        static_assert(!STEADY || NTR < LPC, "the last lane of the cell is the template, not a transient step");
-        bool st = false;
-#ifdef LDSR_STEADY_DEBUG
-        double dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-        double cK = 0.0, cJ = 0.0, cr = 0.0, cVu = 0.0, ch = 0.0, clg = 0.0, X_tr = 0.0;
-        double trJ = 0.0, trG = 0.0, trH = 0.0, trLq = 0.0, trLg = 0.0;
-        auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl) * 2 + (i & 1)]; };
-        if constexpr (STEADY) {
-            const bool trl = vl < NTR;
-            double e_t = tval(0), bu_t = 0.0;                       // (tri is zero for vl >= NTR)
-#pragma unroll
-            for (int q_ = 0; q_ < QQ; q_++) e_t = fma(-th.D[q_], tval(1 + PP + q_), e_t);
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) bu_t = fma(th.B[p_], tval(1 + p_), bu_t);
-            // (a) variance side: inclusive scan of the 2x2 step matrices [[alpha, Q],[C2R, 1]] (one and the
-            // same for every step: scaled by an exact power of two so that max(alpha, 1) c is in
-            // [0.5, 1), as the generic dense F1 does; identity beyond step NTR-1), then
-            // Vp = (p00 V1 + p01) / (p10 V1 + p11) of the lane before
-            double Vp;
-            {
-                const double mxs = fmax(alpha, 1.0);
-                const int ke = -__builtin_amdgcn_frexp_exp(mxs);
-                const double cs = __builtin_amdgcn_ldexp(1.0, ke);
-                double p00 = trl ? alpha * cs : 1.0, p01 = trl ? Q * cs : 0.0;
-                double p10 = trl ? C2R * cs : 0.0, p11 = trl ? cs : 1.0;
-#define VSCAN_ROUND(Q00, Q01, Q10, Q11)                                                      \
-                {                                                                            \
-                    const double q00 = Q00, q01 = Q01, q10 = Q10, q11 = Q11;                 \
-                    const double r00 = fma(p00, q00, p01 * q10), r01 = fma(p00, q01, p01 * q11); \
-                    const double r10 = fma(p10, q00, p11 * q10), r11 = fma(p10, q01, p11 * q11); \
-                    p00 = r00; p01 = r01; p10 = r10; p11 = r11;                              \
-                }
-#define VSCAN_SHR(n) VSCAN_ROUND(dpp1<DPP_ROW_SHR(n)>(p00), dppz<DPP_ROW_SHR(n)>(p01), dppz<DPP_ROW_SHR(n)>(p10), dpp1<DPP_ROW_SHR(n)>(p11))
-                VSCAN_SHR(1) VSCAN_SHR(2) VSCAN_SHR(4)
-                {   // exact power-of-two rescale (projective coordinates are scale free)
-                    const double m = fmax(fmax(fabs(p00), fabs(p01)), fmax(fabs(p10), fabs(p11)));
-                    const int e2 = 1 - __builtin_amdgcn_frexp_exp(m);
-                    p00 = __builtin_amdgcn_ldexp(p00, e2); p01 = __builtin_amdgcn_ldexp(p01, e2);
-                    p10 = __builtin_amdgcn_ldexp(p10, e2); p11 = __builtin_amdgcn_ldexp(p11, e2);
-                }
-                VSCAN_SHR(8)
-                VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
-                            (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
-                if constexpr (LPC == 64)
-                    VSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, p00)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p01)),
-                                (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p10)), (dppd<DPP_ROW_BCAST31, 0xC>(1.0, p11)))
-#undef VSCAN_SHR
-#undef VSCAN_ROUND
-                double n_e = fma(p00, th.V1, p01), d_e = fma(p10, th.V1, p11);
-                n_e = dppd<DPP_WAVE_SHR1, 0xF>(th.V1, n_e);
-                d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
-                if (vl == 0) { n_e = th.V1; d_e = 1.0; }
-                Vp = n_e * fast_rcp(d_e);                            // entering step vl (vl >= NTR: t = NTR)
-            }
-            const double sg = fma(C2, Vp, R);                       // the reference's expressions, as in F2
-            const double r0 = fast_rcp(sg);
-            const double w = Vp * r0;
-            const double K = C * w;                                 // src/EM.cpp:86
-            const double Vu = R * w;                                // :88
-            const double Vp1 = fma(A2, Vu, Q);                      // :76
-            const double AVu = A * Vu;
-            const double J = AVu * fast_rcp(Vp1);                   // :100
-            // (b) mean side: Xp_{t+1} = A (1 - K_t C) Xp_t + (A K_t e_t + B u_t) is affine with the gains
-            // just found: inclusive scan over the lanes, then the reference's expressions from the
-            // exact entry state
-            double Xp;
-            {
-                const double aKt = A * K;
-                double al = trl ? fma(-aKt, C, A) : 1.0, bl = trl ? fma(aKt, e_t, bu_t) : 0.0;
-#define MSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
-                MSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
-                MSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
-                MSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
-                MSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
-                MSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
-                if constexpr (LPC == 64) MSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
-#undef MSCAN_ROUND
-                Xp = fma(al, th.mu1, bl);
-                Xp = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xp);
-                if (vl == 0) Xp = th.mu1;
-            }
-            const double dl = fma(-C, Xp, e_t);
-            const double Xu = fma(K, dl, Xp);                       // :87
-            const double Xp1 = fma(A, Xu, bu_t);                    // :74
-            trJ = J;
-            trG = fma(-J, Xp1, Xu);
-            trH = fma(-J, AVu, Vu);
-            trLq = trl ? dl * r0 * dl : 0.0;                        // :122
-            const double lg = log_pos(sg);
-            trLg = trl ? lg : 0.0;
-            // fixed point reached, and every Sigma of the block positive (a negative one is the
-            // generic sweeps' business: lik = NaN)
-            const bool conv = fabs(Vp1 - Vp) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && J * J < 0.8;
-            const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
-            const unsigned long long cvm = __ballot(conv);
-            constexpr unsigned long long CELL = LPC == 64 ? ~0ull : ((1ull << (LPC & 63)) - 1ull);
-            const unsigned long long hm = (okm >> hbase) & CELL, hc = (cvm >> hbase) & CELL;
-            // (rp >= K0: the first K0 lanes own L steps each, so the block ends on a chunk boundary)
-            st = alive && hm == CELL && ((hc >> (LPC - 1)) & 1ull) != 0ull && rp >= K0 && nl > K0;
-            const int src = hbase | (LPC - 1);
-            cK = shfl_d(K, src); cJ = shfl_d(J, src); cr = shfl_d(r0, src); cVu = shfl_d(Vu, src);
-            ch = shfl_d(trH, src); clg = shfl_d(lg, src); X_tr = shfl_d(Xp, src);
-#ifdef LDSR_STEADY_DEBUG
-            dbg[0] = Xp; dbg[1] = Vp; dbg[2] = trG; dbg[3] = trJ; dbg[11] = st ? 1.0 : 0.0;
-#endif
-        }
-
-        SCAN_TICK(0)       // iteration constants, transient block, verdict
-        if constexpr (STEADY) if (__builtin_expect(st, 1)) {     // (idle halves -- no cell left -- take neither branch)
-            // ============================================ steady sweeps over t = NTR .. T-1
-            // Lane K0-1 keeps only its predicated step L-1 (= step NTR); lanes K0.. their whole chunks.
-            const bool body = act && vl >= K0;
-            const bool tail_s = tail && vl >= K0 - 1;
-            const double aK = A * cK, a = fma(-aK, C, A);           // Xp_{t+1} = a Xp_t + (A K e_t + B u_t)
-            // a^(L-1), J^(L-1): multipliers of a whole chunk
-            double aL = 1.0, JL = 1.0;
-            {
-                double sa = a, sj = cJ;
-                bool have = false;
-#pragma unroll
-                for (int bit = 0; (1 << bit) <= L - 1; bit++) {
-                    if ((L - 1) & (1 << bit)) {
-                        if (!have) { aL = sa; JL = sj; have = true; }
-                        else { aL *= sa; JL *= sj; }
-                    }
-                    if ((2 << bit) <= L - 1) { sa *= sa; sj *= sj; }
-                }
-            }
-            // ---- F1: chunk composite of the affine mean recursion; e_t, B u_t left for F2.
-            // The series image is read PF steps ahead through an explicit register ring pinned by
-            // scheduling barriers: left alone, the scheduler issued each ds_read_b128 right before
-            // its use (one read in flight, 35 ns exposed per read: the sweeps were LDS-latency bound).
-            // (the strip is free here: the steady sweeps have no h_t; J_t's registers stay unused, which
-            // is what makes room for the read-ahead rings at two waves per SIMD)
-            double al = 1.0, bl = 0.0, buLast = 0.0;
-            auto f1s = [&](int j, const double (&w)[2 * KP]) {
-                double e = w[0], bu = 0.0;
-#pragma unroll
-                for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], w[1 + PP + q_], e);
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], w[1 + p_], bu);
-                gv_[j] = e;
-                if constexpr (BUREG) buv[j] = bu;                     // (one cell per wave: registers)
-                else if constexpr (!HREG) { if (j < L - 1) hs[j * 64] = bu; else buLast = bu; }   // B u_t waits for F2 in the wave's LDS strip
-                bl = fma(a, bl, fma(aK, e, bu));
-            };
-            {
-                constexpr bool PRET = KP <= 4;       // the predicated step's values read ahead too (narrow inputs)
-                double Wt[2 * KP], W[PF][2 * KP];
-                if constexpr (PRET) ldw(L - 1, Wt);
-#pragma unroll
-                for (int d = 0; d < PF; d++) ldw(d, W[d]);
-                __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-                if (body) {
-#pragma unroll
-                    for (int j = 0; j < L - 1; j++) {
-                        f1s(j, W[j % PF]);
-                        if (j + PF < L - 1) ldw(j + PF, W[j % PF]);
-                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-                    }
-                    al = aL;
-                }
-                if (tail_s) {
-                    if constexpr (!PRET) ldw(L - 1, Wt);
-                    f1s(L - 1, Wt);
-                    al *= a;
-                }
-            }
-            // ---- inclusive scan over the cell's lanes, then the entry state of this lane
-#define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
-            SSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
-            SSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
-            SSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
-            SSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
-            SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
-            if constexpr (LPC == 64) SSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
-#undef SSCAN_ROUND
-            SCAN_TICK(1)   // steady F1
-            double Xp = fma(al, X_tr, bl);                           // after this lane's steps
-            Xp = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xp);
-            if (vl == 0) Xp = X_tr;
-#ifdef LDSR_STEADY_DEBUG
-            dbg[4] = Xp; dbg[9] = al; dbg[10] = bl;
-#endif
-            // ---- F2: the reference's mean expressions with the steady gains
-            double lq = 0.0, Xu = 0.0;
-            auto f2s = [&](int j, double bu) {
-                const double e = gv_[j];
-                const double dl = fma(-C, Xp, e);
-                lq = fma(dl, dl, lq);                              // :122 (times 1/Sigma below)
-                Xu = fma(cK, dl, Xp);                              // :87
-                const double Xp1 = fma(A, Xu, bu);                 // :74
-                double g = fma(-cJ, Xp1, Xu);
-                if (j >= L - 2) {
-                    const bool fin = (vl == lastLane) && (j == (tail_s ? L - 1 : L - 2));
-                    g = fin ? Xu : g;                              // step T-1: Xs = Xu
-                }
-                gv_[j] = g;
-                Xp = Xp1;
-            };
-            if constexpr (HREG) {
-                auto bu_of = [&](int j) {
-                    if constexpr (BUREG) return buv[j];
-                    double bu = 0.0;
-#pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], val(j, 1 + p_), bu);
-                    return bu;
-                };
-                if (body) {
-#pragma unroll
-                    for (int j = 0; j < L - 1; j++) f2s(j, bu_of(j));
-                }
-                if (tail_s) f2s(L - 1, bu_of(L - 1));
-            } else {
-                if (body) {
-                    double U[PF2];
-#pragma unroll
-                    for (int d = 0; d < PF2; d++) U[d] = hs[d * 64];
-                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-#pragma unroll
-                    for (int j = 0; j < L - 1; j++) {
-                        f2s(j, U[j % PF2]);
-                        if (j + PF2 < L - 1) U[j % PF2] = hs[(j + PF2) * 64];
-                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-                    }
-                }
-                if (tail_s) f2s(L - 1, buLast);
-            }
-            SCAN_TICK(2)   // forward scan, steady F2
-            // B2's first reads of the image are issued here, ahead of the reverse scan
-            constexpr bool PRET2 = KP <= 4;
-            double Vt[2 * KP], V[PF][2 * KP];
-            if constexpr (PRET2) {
-                ldw(L - 1, Vt);
-#pragma unroll
-                for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
-            }
-            __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-            tLv = fma(Xu, Xu, cVu);
-            const int nst = (body ? L - 1 : 0) + (tail_s ? 1 : 0);    // steady steps of this lane
-            likq = fma(cr, lq, trLq);
-            lsp = fma((double)nst, clg, trLg);
-            // ---- reverse composite of the chunk (constant multiplier J), reverse scan
-            double Pi = 1.0, G = 0.0;
-            if (tail_s) { G = gv_[L - 1]; Pi = cJ; }
-            if (body) {
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) G = fma(cJ, G, gv_[j]);
-                Pi *= JL;
-            }
-#define RSCAN_ROUND(n) { const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi), Gb = dppz<DPP_ROW_SHL(n)>(G); G = fma(Pi, Gb, G); Pi *= Pb; }
-            RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
-#undef RSCAN_ROUND
-            {
-                double Hdummy = 0.0;
-                rscan_cross<LPC>(Pi, G, Hdummy, lane);
-            }
-            double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
-            if (vl == LPC - 1) Xn = 0.0;
-            const double XsS = shfl_d(G, hbase | (K0 - 1));         // Xs at t = NTR (step L-1 of lane K0-1)
-#ifdef LDSR_STEADY_DEBUG
-            dbg[5] = Xn; dbg[8] = G;
-#endif
-            SCAN_TICK(3)   // reverse composite and scan
-            // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
-            zero_sums();
-            auto b2s = [&](int j, const double (&w)[2 * KP]) {
-                const double Xs = fma(cJ, Xn, gv_[j]);             // :101
-                aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) {
-                    const double ut = w[1 + p_];                   // zero at t = T-1
-                    aTx1u[p_] = fma(Xn, ut, aTx1u[p_]);            // :190
-                    aTux[p_] = fma(ut, Xs, aTux[p_]);              // :191
-                }
-                aPall = fma(Xs, Xs, aPall);
-                aSyx = fma(w[0], Xs, aSyx);                        // :151
-#pragma unroll
-                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, w[1 + PP + q_], aSxv[q_]);   // :159
-                Xn = Xs;
-            };
-            if constexpr (!PRET2) {
-                if (tail_s) ldw(L - 1, Vt);
-#pragma unroll
-                for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
-            }
-            if (tail_s) b2s(L - 1, Vt);
-            if (body) {
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) {
-                    const int d = (L - 2 - j) % PF;
-                    b2s(j, V[d]);
-                    if (j - PF >= 0) ldw(j - PF, V[d]);
-                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
-                }
-            }
-            SCAN_TICK(4)   // steady B2
-            // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
-            // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
-            const int N = T - NTR;                                   // steps NTR .. T-1
-            const double rho = cJ * cJ;
-            const double romr = fast_rcp(1.0 - rho);
-            const double Vss = ch * romr;
-            const double dV = cVu - Vss;
-            // (rho < 0.8 is part of the verdict and N >= 500: rho^(N-1) < 1e-48 is dropped)
-            const double VsS = Vss;                                  // Vs at t = NTR
-            const double sumVs = fma(dV, romr, (double)N * Vss);     // sum_{t >= NTR} Vs_t
-            addPall = sumVs;                                          // :181,:183
-            addTx1x = cJ * (sumVs - VsS);                             // sum_{t=NTR}^{T-2} Vs_{t+1} J_t  (:180)
-            // ---- transient block backwards: composite of steps vl .. NTR-1 applied to (XsS, VsS)
-            {
-                const bool trl = vl < NTR;
-                // (the block's y, u, v are read from LDS AGAIN: through a lane index the compiler cannot
-                // match with the forward block's, or it keeps all 1 + p + q values alive -- in scratch,
-                // for wide inputs -- across the steady sweeps)
-                int vl2 = vl;
-                asm volatile("" : "+v"(vl2));
-                auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl2) * 2 + (i & 1)]; };
-                double Pt = trl ? trJ : 1.0, Gt = trl ? trG : 0.0, Ht = trl ? trH : 0.0;
-#define RSCAN_ROUND(n)                                                     \
-                {                                                          \
-                    const double Pb = dpp1<DPP_ROW_SHL(n)>(Pt);            \
-                    const double Gb = dppz<DPP_ROW_SHL(n)>(Gt);            \
-                    const double Hb = dppz<DPP_ROW_SHL(n)>(Ht);            \
-                    Gt = fma(Pt, Gb, Gt);                                  \
-                    Ht = fma(Pt * Pt, Hb, Ht);                             \
-                    Pt *= Pb;                                              \
-                }
-                RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
-#undef RSCAN_ROUND
-                rscan_cross<LPC>(Pt, Gt, Ht, lane);     // (full products: the terminal value at t = NTR is not zero)
-                const double XsT = fma(Pt, XsS, Gt), VsT = fma(Pt * Pt, VsS, Ht);   // at step vl (vl >= NTR: at NTR)
-                const double XsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, XsT);
-                const double VsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, VsT);
-                if (trl) {
-                    aTx1x = fma(XsN, XsT, fma(VsN, trJ, aTx1x));     // :180
-#pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) {
-                        const double ut = tval(1 + p_);
-                        aTx1u[p_] = fma(XsN, ut, aTx1u[p_]);
-                        aTux[p_] = fma(ut, XsT, aTux[p_]);
-                    }
-                    aPall += fma(XsT, XsT, VsT);
-                    aSyx = fma(tval(0), XsT, aSyx);
-#pragma unroll
-                    for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(XsT, tval(1 + PP + q_), aSxv[q_]);
-                }
-                X0v = XsT; V0v = VsT;                                // lane 0: Xs_0, Vs_0
-#ifdef LDSR_STEADY_DEBUG
-                dbg[6] = XsT; dbg[7] = VsT;
-#endif
-            }
-        }
-        SCAN_TICK(5)       // closed-form variance sums, transient block backwards
-        if (!st && STEADY && !alive) zero_sums();     // (an idle half: nothing ran)
-        if (!st && (!STEADY || alive)) {
-#ifndef LDSR_STEADY_ONLY_EXPERIMENT   // (timing experiment: no fallback at all -- results wrong for slow cells)
+        SCAN_TICK(0)       // iteration constants, first lead pass
+        if (alive) {
             PairSweepOut<PP, QQ> o;
-            if constexpr (STEADY) pair_generic_sweeps_call<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
-            else pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
+            pair_generic_sweeps<PP, QQ, L, LPC, DENSE>(o, th, ys, hs, obsmask, lane, nl, rp, x_t1, v_t1);
             aSyx = o.aSyx; aTx1x = o.aTx1x; aPall = o.aPall; aSxx = o.aSxx;
             likq = o.likq; lsp = o.lsp; tLv = o.tLv; X0v = o.X0v; V0v = o.V0v; sneg = o.sneg;
 #pragma unroll
             for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = o.aSxv[q_];
 #pragma unroll
             for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = o.aTx1u[p_]; aTux[p_] = o.aTux[p_]; }
-#endif
+        } else {
+            zero_sums();     // (an idle half: nothing ran)
         }
 
-        SCAN_TICK(6)       // the generic sweeps (fallback cells)
+        SCAN_TICK(6)       // the sweeps
         // ------------------------------------------------ LEAD, second pass: Xs_t = Xp_t + c_t delta as it goes
         if constexpr (LEAD) {
             const double dlt = shfl_d(X0v, hbase) - x_t1;            // Xs - Xp at the tail's first step
@@ -1158,7 +694,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             S.X0 = shfl_d(X0v, hbase);               // :218
             S.V0 = shfl_d(V0v, hbase);               // :219
             const double termLast = shfl_d(tLv, hbase | lastLane);
-            if constexpr (STEADY) { red[1] += addTx1x; red[2] += addPall; }
             if constexpr (LEAD) {
                 // eps = Vs - Vp at the tail's first step closes the lead's variance sums; mu1 / V1 come from t = 0
                 const double dlt = S.X0 - x_t1, eps = S.V0 - v_t1;
@@ -1175,7 +710,7 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             }
             const double term0 = fma(S.X0, S.X0, S.V0);
             const unsigned long long negm = __ballot(sneg < 0);
-            const bool neg = ((negm >> hbase) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63)) - 1ull))) != 0;   // log of a negative Sigma
+            const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
             S.Syx = red[0]; S.Tx1x = red[1];
             S.Sxx = DENSE ? red[2] : red[5];
 #pragma unroll
@@ -1213,10 +748,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     for (int k_ = 0; k_ < 10; k_++) prm.liks[(long)cell * prm.niter + k_] = (double)tick_[k_];
 #endif
             }
-#ifdef LDSR_STEADY_DEBUG
-            if (prm.liks && cell == c0 && 16 + 12 * LPC <= prm.niter)
-                for (int i = 0; i < 12; i++) prm.liks[(long)cell * prm.niter + 16 + i * LPC + vl] = dbg[i];
-#endif
             alive = false;
             if constexpr (QUEUE) {
                 if (abort_now) {
@@ -1239,7 +770,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                         cell = c0 + kn;
                         load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
                         white_in(th, (SeriesConstK)sc);
-                        if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
                         it = 0;
                         lik = NAN; lik1 = NAN; lik2 = NAN;
                     }
@@ -1248,7 +778,571 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
         } else {
             mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
         }
-        if constexpr (LPC == 64 && LDSR_W64_UNIFORM) make_uniform(th);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// em_pair_body_steady -- fully observed series, two cells per wave, chunks of L >= 24 steps (T = 737..1024):
+// BASELINE config 2's kernel.
+//
+// With every y_t observed the variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t:
+// src/EM.cpp:76,86,88,100) is the data-independent Riccati recursion, which reaches its fixed point
+// geometrically -- within 31 steps for 99.2 % of the (cell, iteration) pairs of BASELINE config 2 (a numpy
+// replay of the bench grid; 16 % of the cells fail at theta0, 0.4 % after ten iterations).  The first
+// NTR = L-1 steps of the series (the chunk of lane 0 without its predicated step) are done ONE STEP PER
+// LANE (a 2x2 scan of the variance step matrices, an affine scan of the means, the reference's expressions
+// from the exact entry state); lane 31 is no transient step, its "entry state" is the state at t = NTR and
+// what it evaluates there are the steady constants K, 1/Sigma, Vu, J, h, log Sigma.  Verdict, per CELL:
+// one more step leaves Vp unchanged to 2^-48, every Sigma of the block is positive, J^2 < 0.8.  Cells that
+// pass run the STEADY SWEEPS on t >= NTR: only the mean recursions (affine, constant multipliers), 19 fp64
+// operations per step where the generic sweeps take 50, no h_t strip, the variance sums in closed form.
+// Cells that fail (slow Riccati convergence: A near 1 with a small gain, mostly in the first EM
+// iterations) take the generic sweeps for that iteration.
+//
+// TWO LOOPS, ONE PER FORM (round 4).  Round 3 ran the generic sweeps as a `noinline` call inside the steady
+// loop: ~300 scratch accesses around every call (52 MB of spill traffic per launch), and a wave with one
+// slow and one fast cell paid transient block + steady sweeps + call, ~4x a steady iteration.  Now the wave
+// is a two-state machine.  S loop: steady iterations for all its cells; left as soon as a cell fails the
+// verdict.  G loop: generic iterations (pair_generic_sweeps inlined, nothing of the steady form live) for
+// the cells that fail, while a cell that passes WAITS -- its iteration count simply does not advance;
+// left when no cell fails any more.  Each loop body holds one form only, so each gets the register
+// allocation the stand-alone kernels have (no call, no scratch), and a slow iteration costs one generic
+// iteration.  Which form a cell's iteration takes is decided by the cell's own theta (var_block is the
+// same explicit-fma code in both loops), so its arithmetic never depends on its wave partner or on the
+// order in which cells are handed out -- only the time at which it is computed does.
+// series_prep orders the cells of a series by predicted slowness (EmParams.perm, slowest first, dealt
+// across the workgroups): slow cells share waves with slow cells, and the work queue hands them out first.
+template <int PP, int QQ, int L, bool QUEUE>
+__device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const double *ys, double *hs,
+                                                    const double *tri, int s, int c0, int nc, int lane,
+                                                    int wave) {
+    constexpr int LPC = 32;
+    constexpr int KP = scan_pairs(PP, QQ), KV = img_values(PP, QQ);
+    constexpr int NTR = L - 1;
+    static_assert(NTR < LPC, "the last lane of the cell is the template, not a transient step");
+    const int half = lane >> 5, vl = lane & 31, hbase = lane & 32;
+    auto val = [&](int j, int i) -> double { return ys[img_off(j, i, KV, LPC, L) + vl * 2]; };
+    // all K values of step j of this lane (ds_read_b128 each pair)
+    auto ldw = [&](int j, double (&w)[2 * KP]) {
+#pragma unroll
+        for (int i = 0; i < KV; i++) w[i] = val(j, i);
+    };
+    // steady sweeps: steps the image is read ahead (a step is KP 16-byte pairs: wide inputs get a
+    // shorter ring) and the strip
+    constexpr int PF = KP <= 2 ? LDSR_STEADY_PF : (KP <= 4 ? 2 : 1);
+    constexpr int PF2 = LDSR_STEADY_PF2;
+    const int T = prm.T;
+    const int P = 6 + prm.p + prm.q;
+    const SeriesConst *__restrict__ sc = prm.sc + s;
+    const int n_obs = sc->n_obs;
+    const int nl = (T + L - 1) / L;          // active lanes of a half
+    const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
+    const bool act = vl < nl;
+    const bool tail = vl < rp;
+    const int lastLane = nl - 1;             // (within the half) owner of step T-1
+    const bool shape_ok = rp >= 1 && nl > 1; // lane 0 owns L steps: the block ends on a chunk boundary
+    const int *__restrict__ perm = prm.perm; // position -> cell (series_prep: slowest first), or null
+
+    // this half's cell
+    int k = QUEUE ? 0 : 2 * wave + half;
+    if constexpr (QUEUE) {
+        if (vl == 0) k = atomicAdd(prm.queue + s, 1);
+        k = __shfl(k, hbase, 64);
+    }
+    bool alive = k < nc;
+    auto cell_at = [&](int pos) { return perm ? perm[c0 + pos] : c0 + pos; };
+    int cell = cell_at(alive ? k : 0);
+    Theta<PP, QQ> th;
+    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
+    double lik = NAN, lik1 = NAN, lik2 = NAN;
+    int it = 0;
+    int wit = 0;             // wave-uniform iteration count (interrupt poll)
+    bool aborted = false;    // the host raised the interrupt flag
+#ifdef LDSR_SCAN_TIMING
+    unsigned long long tick_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+    const unsigned long long real0_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
+
+    // what the sweeps of either form leave in every lane
+    double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
+    double addPall = 0.0, addTx1x = 0.0;    // steady form: closed-form variance sums of the steady region
+    int sneg = 0;
+    double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0;
+    double aSxv[QQ], aTx1u[PP], aTux[PP];
+    auto zero_sums = [&]() {
+        aSyx = 0.0; aTx1x = 0.0; aPall = 0.0;
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+    };
+
+    // ---- variance side of the transient block, and the verdict.  Explicit fma / mul only: the two loops
+    // each inline a copy and must decide alike.  (a) inclusive scan of the 2x2 step matrices
+    // [[alpha, Q],[C2R, 1]] (one and the same for every step: scaled by an exact power of two so that
+    // max(alpha, 1) c is in [0.5, 1), as the generic dense F1 does; identity beyond step NTR-1), then
+    // Vp = (p00 V1 + p01) / (p10 V1 + p11) of the lane before; (b) the reference's expressions, as in F2.
+    struct VarBlk { double Vp, sg, r0, K, Vu, AVu, J, Vp1; bool st; };
+    auto var_block = [&](double V1, double A, double C, double Q, double R, bool live) -> VarBlk {
+        VarBlk b;
+        const double A2 = A * A, C2 = C * C;
+        const double C2R = C2 * fast_rcp(R), alpha = fma(Q, C2R, A2);
+        const bool trl = vl < NTR;
+        double Vp;
+        {
+            const double mxs = fmax(alpha, 1.0);
+            const int ke = -__builtin_amdgcn_frexp_exp(mxs);
+            const double cs = __builtin_amdgcn_ldexp(1.0, ke);
+            double p00 = trl ? alpha * cs : 1.0, p01 = trl ? Q * cs : 0.0;
+            double p10 = trl ? C2R * cs : 0.0, p11 = trl ? cs : 1.0;
+#define VSCAN_ROUND(Q00, Q01, Q10, Q11)                                                      \
+            {                                                                            \
+                const double q00 = Q00, q01 = Q01, q10 = Q10, q11 = Q11;                 \
+                const double r00 = fma(p00, q00, p01 * q10), r01 = fma(p00, q01, p01 * q11); \
+                const double r10 = fma(p10, q00, p11 * q10), r11 = fma(p10, q01, p11 * q11); \
+                p00 = r00; p01 = r01; p10 = r10; p11 = r11;                              \
+            }
+#define VSCAN_SHR(n) VSCAN_ROUND(dpp1<DPP_ROW_SHR(n)>(p00), dppz<DPP_ROW_SHR(n)>(p01), dppz<DPP_ROW_SHR(n)>(p10), dpp1<DPP_ROW_SHR(n)>(p11))
+            VSCAN_SHR(1) VSCAN_SHR(2) VSCAN_SHR(4)
+            {   // exact power-of-two rescale (projective coordinates are scale free)
+                const double m = fmax(fmax(fabs(p00), fabs(p01)), fmax(fabs(p10), fabs(p11)));
+                const int e2 = 1 - __builtin_amdgcn_frexp_exp(m);
+                p00 = __builtin_amdgcn_ldexp(p00, e2); p01 = __builtin_amdgcn_ldexp(p01, e2);
+                p10 = __builtin_amdgcn_ldexp(p10, e2); p11 = __builtin_amdgcn_ldexp(p11, e2);
+            }
+            VSCAN_SHR(8)
+            VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
+                        (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
+#undef VSCAN_SHR
+#undef VSCAN_ROUND
+            double n_e = fma(p00, V1, p01), d_e = fma(p10, V1, p11);
+            n_e = dppd<DPP_WAVE_SHR1, 0xF>(V1, n_e);
+            d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
+            if (vl == 0) { n_e = V1; d_e = 1.0; }
+            Vp = n_e * fast_rcp(d_e);                            // entering step vl (vl >= NTR: t = NTR)
+        }
+        const double sg = fma(C2, Vp, R);
+        const double r0 = fast_rcp(sg);
+        const double w = Vp * r0;
+        b.K = C * w;                                             // src/EM.cpp:86
+        b.Vu = R * w;                                            // :88
+        b.Vp1 = fma(A2, b.Vu, Q);                                // :76
+        b.AVu = A * b.Vu;
+        b.J = b.AVu * fast_rcp(b.Vp1);                           // :100
+        b.Vp = Vp; b.sg = sg; b.r0 = r0;
+        // fixed point reached, and every Sigma of the block positive (a negative one is the generic
+        // sweeps' business: lik = NaN); J^2 < 0.8, which a converged Riccati recursion implies unless V1
+        // happens to be the fixed point itself, lets the closed-form variance sums drop J^(2(T-NTR))
+        const double dV = b.Vp1 - Vp;
+        const bool conv = fabs(dV) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && b.J * b.J < 0.8;
+        const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
+        const unsigned long long cvm = __ballot(conv);
+        constexpr unsigned long long CELL = (1ull << LPC) - 1ull;
+        const unsigned long long hm = (okm >> hbase) & CELL, hc = (cvm >> hbase) & CELL;
+        b.st = live && hm == CELL && ((hc >> (LPC - 1)) & 1ull) != 0ull && shape_ok;
+        return b;
+    };
+
+    // ---- the rest of an iteration for the halves in `active` (the cells whose sweeps just ran): one
+    // reduction per half, likelihood, stop rule, M-step; a cell that stops stores its result and -- work
+    // queue -- its half pulls the next one.  The other halves keep their state untouched.
+    auto finish_iteration = [&](bool active, bool steady_form) {
+        Sums<PP, QQ> S;
+        {
+            constexpr int NB = 5;
+            constexpr int NR = NB + QQ + 2 * PP;
+            double red[NR];
+            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) red[NB + q_] = aSxv[q_];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = aTx1u[p_]; red[NB + QQ + PP + p_] = aTux[p_]; }
+            // recursive halving over the half's 32 lanes (em_scan_impl.h), then every lane fetches
+            // the totals from their home lanes of its own half
+            red_rounds<NR, LPC / 2>(red, lane);
+            {
+                const double tt = red[0];
+#pragma unroll
+                for (int i = 0; i < NR; i++) red[i] = shfl_d(tt, hbase | red_home(i, NR, LPC));
+            }
+            S.X0 = shfl_d(X0v, hbase);               // :218
+            S.V0 = shfl_d(V0v, hbase);               // :219
+            const double termLast = shfl_d(tLv, hbase | lastLane);
+            if (steady_form) { red[1] += addTx1x; red[2] += addPall; }
+            const double term0 = fma(S.X0, S.X0, S.V0);
+            const unsigned long long negm = __ballot(sneg < 0);
+            const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
+            S.Syx = red[0]; S.Tx1x = red[1];
+            S.Sxx = red[2];
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) S.Sxv[q_] = red[NB + q_];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { S.Tx1u[p_] = red[NB + QQ + p_]; S.Tux[p_] = red[NB + QQ + PP + p_]; }
+            S.Txx = red[2] - termLast;
+            S.Tx1x1 = red[2] - term0;
+            if (active) {
+                lik2 = lik1;
+                lik1 = lik;
+                lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;   // :113-124
+                if (neg) lik = NAN;
+            }
+        }
+        SCAN_TICK(8)       // reduction, likelihood
+        int abort_now = 0;
+        if (prm.abort && ((++wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
+            abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
+        if (abort_now) aborted = true;
+        if (active && prm.liks && vl == 0) prm.liks[(long)cell * prm.niter + it] = lik;
+        if (active) it++;
+        bool stop = active && it >= prm.niter;
+        if (active && it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;   // :272
+        if (alive && abort_now) stop = true;       // (a waiting cell stops too)
+        if (alive && stop) {
+            // theta stays the one that produced this fit (:276-279)
+            white_out(th, (SeriesConstK)sc);
+            if (vl == 0) {
+                store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+                if (prm.liks && prm.liks_nanfill)
+                    for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+                prm.n_iter[cell] = it;
+                prm.lik[cell] = lik;
+                prm.status[cell] = (abort_now && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
+#ifdef LDSR_SCAN_TIMING
+                tick_[9] = __builtin_amdgcn_s_memrealtime() - real0_;      // -> shader clock = cycles / this x 100 MHz
+                if (prm.liks && prm.niter >= 10)
+                    for (int k_ = 0; k_ < 10; k_++) prm.liks[(long)cell * prm.niter + k_] = (double)tick_[k_];
+#endif
+            }
+            alive = false;
+            if constexpr (QUEUE) {
+                if (abort_now) {
+                    // drain the queue: what it still holds is marked, not computed (an
+                    // LDSR_EINTERRUPTED return never leaves stale numbers that look like results)
+                    for (int pulls = 0; pulls <= nc; pulls++) {
+                        int kn = 0;
+                        if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
+                        kn = __shfl(kn, hbase, 64);
+                        if (kn >= nc) break;
+                        if (vl == 0) mark_cell_interrupted(prm, cell_at(kn));
+                    }
+                } else {
+                    int kn = 0;
+                    if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
+                    kn = __shfl(kn, hbase, 64);
+                    if (kn < nc) {
+                        alive = true;
+                        cell = cell_at(kn);
+                        load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+                        white_in(th, (SeriesConstK)sc);
+                        it = 0;
+                        lik = NAN; lik1 = NAN; lik2 = NAN;
+                    }
+                }
+            }
+        } else if (active) {
+            mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
+        }
+    };
+
+    bool go_g = false;       // the S loop met a cell that fails the verdict
+    bool slow = false;       // G loop: this half's cell takes the generic sweeps in this iteration
+    while (__any(alive)) {
+        // ================================================================= S loop: steady iterations
+        while (__any(alive)) {
+            SCAN_TICK(7)       // M-step, stop rule, loop
+            const double A = th.A, C = th.C, Q = th.Q;
+            const VarBlk vb = var_block(th.V1, A, C, Q, th.R, alive);
+            const bool st = vb.st;
+            slow = alive && !st;
+            if (__builtin_expect(__any(slow), 0)) { go_g = true; break; }
+            // ---- mean side of the transient block: Xp_{t+1} = A (1 - K_t C) Xp_t + (A K_t e_t + B u_t) is
+            // affine with the gains just found: inclusive scan over the lanes, then the reference's
+            // expressions from the exact entry state
+            const bool trl = vl < NTR;
+            auto tval = [&](int i) -> double { return tri[((i >> 1) * LPC + vl) * 2 + (i & 1)]; };
+            double e_t = tval(0), bu_t = 0.0;                       // (tri is zero for vl >= NTR)
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) e_t = fma(-th.D[q_], tval(1 + PP + q_), e_t);
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) bu_t = fma(th.B[p_], tval(1 + p_), bu_t);
+            const double K = vb.K, J = vb.J, Vu = vb.Vu, AVu = vb.AVu, r0 = vb.r0;
+            double Xp;
+            {
+                const double aKt = A * K;
+                double al = trl ? fma(-aKt, C, A) : 1.0, bl = trl ? fma(aKt, e_t, bu_t) : 0.0;
+#define MSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
+                MSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+#undef MSCAN_ROUND
+                Xp = fma(al, th.mu1, bl);
+                Xp = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xp);
+                if (vl == 0) Xp = th.mu1;
+            }
+            const double dl = fma(-C, Xp, e_t);
+            const double Xu = fma(K, dl, Xp);                       // :87
+            const double Xp1 = fma(A, Xu, bu_t);                    // :74
+            const double trJ = J;
+            const double trG = fma(-J, Xp1, Xu);
+            const double trH = fma(-J, AVu, Vu);
+            const double trLq = trl ? dl * r0 * dl : 0.0;           // :122
+            const double lg = log_pos(vb.sg);
+            const double trLg = trl ? lg : 0.0;
+            const int src = hbase | (LPC - 1);
+            const double cK = shfl_d(K, src), cJ = shfl_d(J, src), cr = shfl_d(r0, src), cVu = shfl_d(Vu, src);
+            const double ch = shfl_d(trH, src), clg = shfl_d(lg, src), X_tr = shfl_d(Xp, src);
+            likq = 0.0; lsp = 0.0; tLv = 0.0; X0v = 0.0; V0v = 0.0; addPall = 0.0; addTx1x = 0.0; sneg = 0;
+
+            SCAN_TICK(0)       // iteration constants, transient block, verdict
+            if (st) {          // (idle halves -- no cell left -- skip the sweeps)
+                // ============================================ steady sweeps over t = NTR .. T-1
+                // Lane 0 keeps only its predicated step L-1 (= step NTR); lanes 1.. their whole chunks.
+                const bool body = act && vl >= 1;
+                const bool tail_s = tail;
+                const double aK = A * cK, a = fma(-aK, C, A);           // Xp_{t+1} = a Xp_t + (A K e_t + B u_t)
+                // a^(L-1), J^(L-1): multipliers of a whole chunk
+                double aL = 1.0, JL = 1.0;
+                {
+                    double sa = a, sj = cJ;
+                    bool have = false;
+#pragma unroll
+                    for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+                        if ((L - 1) & (1 << bit)) {
+                            if (!have) { aL = sa; JL = sj; have = true; }
+                            else { aL *= sa; JL *= sj; }
+                        }
+                        if ((2 << bit) <= L - 1) { sa *= sa; sj *= sj; }
+                    }
+                }
+                // ---- F1: chunk composite of the affine mean recursion; e_t, B u_t left for F2.
+                // The series image is read PF steps ahead through an explicit register ring pinned by
+                // scheduling barriers: left alone, the scheduler issued each ds_read_b128 right before
+                // its use (one read in flight, 35 ns exposed per read: the sweeps were LDS-latency bound).
+                // (the strip is free here: the steady sweeps have no h_t; J_t's registers stay unused, which
+                // is what makes room for the read-ahead rings at two waves per SIMD)
+                double gv_[L];           // e_t, then g_t of this lane's steps
+                double al = 1.0, bl = 0.0, buLast = 0.0;
+                auto f1s = [&](int j, const double (&w)[2 * KP]) {
+                    double e = w[0], bu = 0.0;
+#pragma unroll
+                    for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], w[1 + PP + q_], e);
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], w[1 + p_], bu);
+                    gv_[j] = e;
+                    if (j < L - 1) hs[j * 64] = bu; else buLast = bu;   // B u_t waits for F2 in the wave's LDS strip
+                    bl = fma(a, bl, fma(aK, e, bu));
+                };
+                {
+                    constexpr bool PRET = KP <= 4;       // the predicated step's values read ahead too (narrow inputs)
+                    double Wt[2 * KP], W[PF][2 * KP];
+                    if constexpr (PRET) ldw(L - 1, Wt);
+#pragma unroll
+                    for (int d = 0; d < PF; d++) ldw(d, W[d]);
+                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    if (body) {
+#pragma unroll
+                        for (int j = 0; j < L - 1; j++) {
+                            f1s(j, W[j % PF]);
+                            if (j + PF < L - 1) ldw(j + PF, W[j % PF]);
+                            __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                        }
+                        al = aL;
+                    }
+                    if (tail_s) {
+                        if constexpr (!PRET) ldw(L - 1, Wt);
+                        f1s(L - 1, Wt);
+                        al *= a;
+                    }
+                }
+                // ---- inclusive scan over the cell's lanes, then the entry state of this lane
+#define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
+                SSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
+                SSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
+                SSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
+                SSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
+                SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+#undef SSCAN_ROUND
+                SCAN_TICK(1)   // steady F1
+                double Xq = fma(al, X_tr, bl);                           // after this lane's steps
+                Xq = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xq);
+                if (vl == 0) Xq = X_tr;
+                // ---- F2: the reference's mean expressions with the steady gains
+                double lq = 0.0, Xuq = 0.0;
+                auto f2s = [&](int j, double bu) {
+                    const double e = gv_[j];
+                    const double dlq = fma(-C, Xq, e);
+                    lq = fma(dlq, dlq, lq);                            // :122 (times 1/Sigma below)
+                    Xuq = fma(cK, dlq, Xq);                            // :87
+                    const double Xq1 = fma(A, Xuq, bu);                // :74
+                    double g = fma(-cJ, Xq1, Xuq);
+                    if (j >= L - 2) {
+                        const bool fin = (vl == lastLane) && (j == (tail_s ? L - 1 : L - 2));
+                        g = fin ? Xuq : g;                             // step T-1: Xs = Xu
+                    }
+                    gv_[j] = g;
+                    Xq = Xq1;
+                };
+                if (body) {
+                    double U[PF2];
+#pragma unroll
+                    for (int d = 0; d < PF2; d++) U[d] = hs[d * 64];
+                    __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+#pragma unroll
+                    for (int j = 0; j < L - 1; j++) {
+                        f2s(j, U[j % PF2]);
+                        if (j + PF2 < L - 1) U[j % PF2] = hs[(j + PF2) * 64];
+                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    }
+                }
+                if (tail_s) f2s(L - 1, buLast);
+                SCAN_TICK(2)   // forward scan, steady F2
+                // B2's first reads of the image are issued here, ahead of the reverse scan
+                constexpr bool PRET2 = KP <= 4;
+                double Vt[2 * KP], V[PF][2 * KP];
+                if constexpr (PRET2) {
+                    ldw(L - 1, Vt);
+#pragma unroll
+                    for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+                }
+                __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                tLv = fma(Xuq, Xuq, cVu);
+                const int nst = (body ? L - 1 : 0) + (tail_s ? 1 : 0);    // steady steps of this lane
+                likq = fma(cr, lq, trLq);
+                lsp = fma((double)nst, clg, trLg);
+                // ---- reverse composite of the chunk (constant multiplier J), reverse scan
+                double Pi = 1.0, G = 0.0;
+                if (tail_s) { G = gv_[L - 1]; Pi = cJ; }
+                if (body) {
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) G = fma(cJ, G, gv_[j]);
+                    Pi *= JL;
+                }
+#define RSCAN_ROUND(n) { const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi), Gb = dppz<DPP_ROW_SHL(n)>(G); G = fma(Pi, Gb, G); Pi *= Pb; }
+                RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+                {
+                    double Hdummy = 0.0;
+                    rscan_cross<LPC>(Pi, G, Hdummy, lane);
+                }
+                double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+                if (vl == LPC - 1) Xn = 0.0;
+                const double XsS = shfl_d(G, hbase);                    // Xs at t = NTR (step L-1 of lane 0)
+                SCAN_TICK(3)   // reverse composite and scan
+                // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
+                zero_sums();
+                auto b2s = [&](int j, const double (&w)[2 * KP]) {
+                    const double Xs = fma(cJ, Xn, gv_[j]);             // :101
+                    aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) {
+                        const double ut = w[1 + p_];                   // zero at t = T-1
+                        aTx1u[p_] = fma(Xn, ut, aTx1u[p_]);            // :190
+                        aTux[p_] = fma(ut, Xs, aTux[p_]);              // :191
+                    }
+                    aPall = fma(Xs, Xs, aPall);
+                    aSyx = fma(w[0], Xs, aSyx);                        // :151
+#pragma unroll
+                    for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, w[1 + PP + q_], aSxv[q_]);   // :159
+                    Xn = Xs;
+                };
+                if constexpr (!PRET2) {
+                    if (tail_s) ldw(L - 1, Vt);
+#pragma unroll
+                    for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+                }
+                if (tail_s) b2s(L - 1, Vt);
+                if (body) {
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) {
+                        const int d = (L - 2 - j) % PF;
+                        b2s(j, V[d]);
+                        if (j - PF >= 0) ldw(j - PF, V[d]);
+                        __builtin_amdgcn_sched_barrier(LDSR_STEADY_SBMASK);
+                    }
+                }
+                SCAN_TICK(4)   // steady B2
+                // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
+                // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
+                const int N = T - NTR;                                   // steps NTR .. T-1
+                const double rho = cJ * cJ;
+                const double romr = fast_rcp(1.0 - rho);
+                const double Vss = ch * romr;
+                const double dV = cVu - Vss;
+                // (rho < 0.8 is part of the verdict and N >= 500: rho^(N-1) < 1e-48 is dropped)
+                const double VsS = Vss;                                  // Vs at t = NTR
+                const double sumVs = fma(dV, romr, (double)N * Vss);     // sum_{t >= NTR} Vs_t
+                addPall = sumVs;                                          // :181,:183
+                addTx1x = cJ * (sumVs - VsS);                             // sum_{t=NTR}^{T-2} Vs_{t+1} J_t  (:180)
+                // ---- transient block backwards: composite of steps vl .. NTR-1 applied to (XsS, VsS)
+                {
+                    // (the block's y, u, v are read from LDS AGAIN: through a lane index the compiler cannot
+                    // match with the forward block's, or it keeps all 1 + p + q values alive -- in scratch,
+                    // for wide inputs -- across the steady sweeps)
+                    int vl2 = vl;
+                    asm volatile("" : "+v"(vl2));
+                    auto tval2 = [&](int i) -> double { return tri[((i >> 1) * LPC + vl2) * 2 + (i & 1)]; };
+                    double Pt = trl ? trJ : 1.0, Gt = trl ? trG : 0.0, Ht = trl ? trH : 0.0;
+#define RSCAN_ROUND(n)                                                     \
+                    {                                                          \
+                        const double Pb = dpp1<DPP_ROW_SHL(n)>(Pt);            \
+                        const double Gb = dppz<DPP_ROW_SHL(n)>(Gt);            \
+                        const double Hb = dppz<DPP_ROW_SHL(n)>(Ht);            \
+                        Gt = fma(Pt, Gb, Gt);                                  \
+                        Ht = fma(Pt * Pt, Hb, Ht);                             \
+                        Pt *= Pb;                                              \
+                    }
+                    RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+                    rscan_cross<LPC>(Pt, Gt, Ht, lane);     // (full products: the terminal value at t = NTR is not zero)
+                    const double XsT = fma(Pt, XsS, Gt), VsT = fma(Pt * Pt, VsS, Ht);   // at step vl (vl >= NTR: at NTR)
+                    const double XsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, XsT);
+                    const double VsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, VsT);
+                    if (trl) {
+                        aTx1x = fma(XsN, XsT, fma(VsN, trJ, aTx1x));     // :180
+#pragma unroll
+                        for (int p_ = 0; p_ < PP; p_++) {
+                            const double ut = tval2(1 + p_);
+                            aTx1u[p_] = fma(XsN, ut, aTx1u[p_]);
+                            aTux[p_] = fma(ut, XsT, aTux[p_]);
+                        }
+                        aPall += fma(XsT, XsT, VsT);
+                        aSyx = fma(tval2(0), XsT, aSyx);
+#pragma unroll
+                        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(XsT, tval2(1 + PP + q_), aSxv[q_]);
+                    }
+                    X0v = XsT; V0v = VsT;                                // lane 0: Xs_0, Vs_0
+                }
+            } else {
+                zero_sums();       // (an idle half: nothing ran)
+            }
+            SCAN_TICK(5)       // closed-form variance sums, transient block backwards
+            finish_iteration(st, true);
+        }
+        if (__builtin_expect(!go_g, 1)) break;
+        go_g = false;
+        // ================================================================= G loop: generic iterations
+        // (entered with `slow` from the S loop's verdict: at least one iteration runs)
+        do {
+            SCAN_TICK(7)
+            {
+                PairSweepOut<PP, QQ> o;
+                pair_generic_sweeps<PP, QQ, L, LPC, true>(o, th, ys, hs, 0u, lane, nl, rp, th.mu1, th.V1);
+                aSyx = o.aSyx; aTx1x = o.aTx1x; aPall = o.aPall;
+                likq = o.likq; lsp = o.lsp; tLv = o.tLv; X0v = o.X0v; V0v = o.V0v; sneg = o.sneg;
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = o.aSxv[q_];
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = o.aTx1u[p_]; aTux[p_] = o.aTux[p_]; }
+            }
+            SCAN_TICK(6)       // the generic sweeps
+            finish_iteration(slow, false);
+            const VarBlk vb = var_block(th.V1, th.A, th.C, th.Q, th.R, alive);
+            slow = alive && !vb.st;
+        } while (__any(slow));
     }
 }
 
@@ -1267,7 +1361,7 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
     // LEAD: the (whitened) u_t of the all-missing first prm.lead steps, [step of the lane][lane][PP],
     // behind the strips
-    constexpr long STRIP = pair_hreg(LPC) ? 0 : pair_strip_doubles(L);     // (one cell per wave: no strips)
+    constexpr long STRIP = pair_strip_doubles(L);
     double *lu = smem + IMG + (long)(blockDim.x >> 6) * STRIP;
     if constexpr (LEAD) {
         const int n3 = ((prm.lead + LPC - 1) / LPC) * LPC * PP;
@@ -1282,7 +1376,8 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
         constexpr int NTR = pair_steady_ntr(L, LPC);
         for (int i = threadIdx.x; i < KP * LPC * 2; i += blockDim.x) {
             const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;      // step l = step l % L of lane l / L
-            lu[i] = l < NTR ? gimg[(((l % L) * KP + m) * LPC + l / L) * 2 + c] : 0.0;
+            const int vi = 2 * m + c;                                         // (an odd K leaves the last half-pair zero)
+            lu[i] = (l < NTR && vi < img_values(PP, QQ)) ? gimg[img_off(l % L, vi, img_values(PP, QQ), LPC, L) + (l / L) * 2] : 0.0;
         }
     }
     __syncthreads();
@@ -1306,10 +1401,14 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     double *hs = smem + IMG + (long)wave * STRIP + lane;
     const bool dense = sc->n_obs == prm.T;
     if constexpr (LEAD) {
-        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
+        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, s, c0, nc, lane, wave);
     } else {
-        if (dense) em_pair_body<PP, QQ, L, LPC, true, QUEUE, false, STEADY>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
-        else em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, tri, s, c0, nc, lane, wave);
+        if (dense) {
+            if constexpr (STEADY) em_pair_body_steady<PP, QQ, L, QUEUE>(prm, smem, hs, tri, s, c0, nc, lane, wave);
+            else em_pair_body<PP, QQ, L, LPC, true, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+        } else {
+            em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+        }
     }
 }
 

@@ -305,14 +305,21 @@ __device__ __forceinline__ PMat pdpp(const PMat &m) {
 //
 // Series image: the K = 1 + PP + QQ values of one time step -- value 0 = y (0 where missing /
 // unused), values 1..PP = u (zero for t = T-1), values 1+PP.. = v -- are stored in PAIRS, 16 bytes
-// per lane: pair m of step j of virtual lane l at doubles [((j*KP + m)*NL + l)*2 + {0,1}],
-// KP = ceil(K/2) (an odd K leaves the last half-pair zero).  Two values then come with ONE
-// ds_read_b128 (4 LDS cycles per wave) where two separate 8-byte rows were fused by the
-// compiler into ds_read2st64_b64 (8 cycles): the LDS pipe, shared by the 8 waves of a CU, was
-// 65-85 % busy with those.
+// per lane: pair m < KH = K/2 of step j of virtual lane l at doubles [((j*KH + m)*NL + l)*2 + {0,1}].
+// Two values then come with ONE ds_read_b128 (4 LDS cycles per wave) where two separate 8-byte rows
+// were fused by the compiler into ds_read2st64_b64 (8 cycles): the LDS pipe, shared by the 8 waves of
+// a CU, was 65-85 % busy with those.
+// An odd K leaves one value per step over.  Until round 3 it sat in a half-empty pair of its own: read
+// alone it is a ds_read_b64 at a 16-byte lane stride -- lanes l and l+16 of a 32-lane group on the same
+// banks, a 2-way conflict -- and the compiler fused the reads of two steps into ds_read2st64_b64 (8 LDS
+// cycles + 8 of conflicts): 11.8 % of config 3's LDS cycles were bank conflicts
+// (profiles/r03_cfg3_pmc_sq2.csv).  Now the odd values of steps 2jj and 2jj+1 share a pair, in a block
+// behind the full pairs: [L*KH*NL*2 + (jj*NL + l)*2 + (j & 1)] -- one conflict-free ds_read_b128 per
+// TWO steps, and the image is K instead of K+1 doubles per lane and step (config 3: 104 KB, was 112).
 __host__ __device__ constexpr int scan_pairs(int PP, int QQ) { return (1 + PP + QQ + 1) / 2; }
+// (img_values / img_doubles / img_off: ldsr_device.h, shared with series_prep_kernel)
 __host__ __device__ constexpr long scan_image_doubles(int L, int W, int PP, int QQ) {
-    return (long)64 * W * L * 2 * scan_pairs(PP, QQ);
+    return img_doubles(L, 64 * W, PP, QQ);
 }
 // per-wave exchange records of a multi-wave cell (doubles): forward composite (8), reverse
 // composite (4), partial sums (XCH_SUMS), plus one slot for the queue pull
@@ -482,20 +489,20 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     // Global image: raw buffer loads -- ONE VGPR holds the lane's byte offset and the pair offset
     // travels in the scalar soffset operand (plain global loads made the compiler keep a 64-bit
     // address pair per 4 KiB window and spill ~400 VGPRs).
-    constexpr int KP = scan_pairs(PP, QQ);
+    constexpr int KV = img_values(PP, QQ);
     constexpr bool BIGIMG = !GIMG && LDSR_SCAN_HI_BASE && (long)scan_image_doubles(L, W, PP, QQ) * 8 > 65536;
     int hi_pairs = 4096;       // (in 16-byte pairs, so that the far base keeps the alignment ds_read_b128 needs)
     if constexpr (BIGIMG) asm volatile("" : "+v"(hi_pairs));
     const double *ys_hi = ys + 2 * hi_pairs;
     auto val = [&](int j, int i) -> double {
         if constexpr (GIMG) {
-            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, vl * 16, (((j * KP + (i >> 1)) * NL) * 2 + (i & 1)) * 8, 0);
+            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, vl * 16, img_off(j, i, KV, NL, L) * 8, 0);
             return __hiloint2double((int)w.y, (int)w.x);
         } else {
             // Images beyond 64 KiB: a ds_read's immediate offset has 16 bits, and the compiler formed the
             // address of every far element with its own v_add_u32 (80 per EM iteration at (4,8), L = 16).
             // A second base 64 KiB up, opaque to the compiler, serves the far half with immediates again.
-            const int e = (j * KP + (i >> 1)) * NL * 2 + (i & 1);
+            const int e = img_off(j, i, KV, NL, L);
             if (BIGIMG && e >= 8192) return ys_hi[e - 8192 + vl * 2];
             return ys[e + vl * 2];
         }

@@ -8,10 +8,6 @@
 #include "em_pair_impl.h"
 #include "ldsr_kernels.h"
 
-#ifndef LDSR_HAVE_WAVE64     // make WAVE64=1: also build em_wave_L13..16.hip (one cell per wave, wide inputs)
-#define LDSR_HAVE_WAVE64 0
-#endif
-
 static const size_t kLdsBytes = 160 * 1024;
 
 // waves per block so that a CU holds ~8 waves given the LDS image of one series
@@ -106,21 +102,6 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
     PairPlan p;
     p.lpc = lpc;
-    if (lpc == 64) {
-#if !LDSR_HAVE_WAVE64
-        return p;       // (not built by default: see the note at em_pair_impl.h pair_hreg)
-#endif
-        // ONE cell per wave for the wide shapes (padded p or q = 8) of fully observed series: the
-        // scan kernel's plan and series image (64 virtual lanes, chunks of 13..16 steps), the pair
-        // family's body with its steady-state sweeps; h_t and B u_t in registers, no strips.
-        const ScanPlan sp = scan_plan(T, PP, QQ);
-        if (!sp.ok || sp.W != 1 || sp.gimg || sp.L < 13 || sp.L > 16 || (PP != 8 && QQ != 8)) return p;
-        if (!pair_steady(sp.L, 64, PP, QQ)) return p;
-        p.L = sp.L;
-        p.wpb = sp.cpb;
-        p.ok = true;
-        return p;
-    }
     // Wide inputs (padded p or q = 8) exist as the two-cells-per-wave LEAD form only: the tail of a
     // closed-form lead in chunks of <= 16 steps (the generic sweeps of long chunks do not fit the
     // registers of two waves per SIMD at q = 8; the lead itself never touches v_t).
@@ -153,7 +134,6 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
 int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
     const PairPlan p = pair_plan(T, PP, QQ, lpc, lead > 0);
     if (!p.ok) return 0;
-    if (lpc == 64) return p.wpb;
     static const int wpb_env = [] { const char *e = getenv("LDSR_PAIR_WPB"); return e ? atoi(e) : 0; }();
     if (wpb_env == 8) return 8;
     const int w = wpb_env == 2 ? 2 : 4;
@@ -186,19 +166,6 @@ hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_bl
     p.wpb = em_pair_waves_per_block(prm.T - prm.lead, PP, QQ, lpc, prm.lead);
 #define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \
                                              : launch_em_pair_L<Lv, 16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-#if LDSR_HAVE_WAVE64
-    if (lpc == 64) {
-        switch (p.L) {
-            case 13: return launch_em_pair_L<13, 64>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-            case 14: return launch_em_pair_L<14, 64>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-            case 15: return launch_em_pair_L<15, 64>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-            case 16: return launch_em_pair_L<16, 64>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
-#else
-    if (lpc == 64) return hipErrorInvalidValue;
-#endif
     switch (p.L) {
         case 3: return launch_em_pair_L<3, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
         case 4: return launch_em_pair_L<4, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);

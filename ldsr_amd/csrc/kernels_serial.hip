@@ -93,10 +93,117 @@ __device__ __forceinline__ double prep_wave_sum(double x) {
     return x;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Cell order for the steady form of the pair kernel (em_pair_impl.h em_pair_body_steady).
+// A fully observed cell takes the steady sweeps in an EM iteration when the prior-variance
+// recursion Vp_{t+1} = (alpha Vp_t + Q) / (g Vp_t + 1), g = C^2 / R, alpha = A^2 + Q g
+// (src/EM.cpp:76,86-88 without missing steps) has settled within the kernel's transient block.
+// The recursion is ONE Moebius map iterated: with its fixed points V+ > 0 > V- and
+// rho = lambda- / lambda+ = A^2 / lambda+^2 (eigenvalues of [[alpha, Q],[g, 1]]) the cross ratio
+// (V_t - V+) / (V_t - V-) = rho^t (V_1 - V+) / (V_1 - V-) gives the number of steps until the
+// relative distance to V+ is below 2^-48 in closed form.  Cells that need more than the block
+// run generic iterations first (16 % of BASELINE config 2's cells at theta0, for 2..31 iterations).
+// Sorting the cells by that prediction puts slow cells into the same waves (a wave of two slow
+// cells runs ONE generic iteration for both; a slow and a fast cell make the fast one wait) and
+// lets the work queue hand out the longest jobs first.  Only the schedule depends on the order:
+// a cell's arithmetic does not (tests/test_gpu_pair.py).
+__device__ static double steady_settle_steps(double A, double C, double Q, double R, double V1) {
+    const double A2 = A * A, g = C * C / R, alpha = A2 + Q * g;
+    const double d = alpha - 1.0, disc = d * d + 4.0 * Q * g, sq = sqrt(disc);
+    const double lp = 0.5 * (alpha + 1.0 + sq), rho = A2 / (lp * lp);
+    if (!(rho < 1.0) || !(disc >= 0.0) || !(R > 0.0) || !(Q > 0.0) || !(V1 > 0.0)) return 1.0e9;
+    if (!(rho > 0.0)) return 1.0;
+    const double Vp = d >= 0.0 ? (d + sq) / (2.0 * g) : 2.0 * Q / (sq - d);      // V+ (no cancellation either way)
+    if (!(Vp > 0.0) || !(Vp < 1.0e300)) return 1.0e9;
+    const double J = A * R / (C * C * Vp + R);                                   // steady J = A Vu / Vp (:100)
+    if (!(J * J < 0.8)) return 1.0e9;                                            // (the kernel's verdict asks for it)
+    const double r = 2.0 * sq / (2.0 * g * V1 - d + sq);                         // (V+ - V-) / (V1 - V-)
+    const double dev0 = fabs(V1 - Vp) * fabs(r) / Vp;
+    if (!(dev0 > 3.552713678800501e-15)) return 0.0;
+    return log(3.552713678800501e-15 / dev0) / log(rho);
+}
+
+// One workgroup (1024 threads) per series: stable counting sort of the cells into 8 buckets of
+// predicted slowness, slowest first; sorted index -> position by the launch's schedule.
+__device__ static void order_cells(const PrepParams &prm, int s) {
+    constexpr int NB = 8, NW = 16;
+    __shared__ int hist[NB], start[NB], wcnt[NW][NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
+    const int base = prm.cell_off[s], n = prm.cell_off[s + 1] - base;
+    const int P = 6 + prm.p + prm.q;
+    const double ntr = (double)prm.order_ntr;
+    if (tid < NB) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const double *t = prm.theta0 + (long)(base + i) * P;
+        const double st = steady_settle_steps(t[0], t[1 + prm.p], t[2 + prm.p + prm.q], t[3 + prm.p + prm.q], t[5 + prm.p + prm.q]);
+        const double x = st / ntr;
+        const int b = x > 16.0 ? 0 : x > 8.0 ? 1 : x > 4.0 ? 2 : x > 2.0 ? 3 : x > 1.4 ? 4 : x > 1.05 ? 5 : x > 0.8 ? 6 : 7;
+        prm.perm_key[base + i] = b;
+        atomicAdd(&hist[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int b = 0; b < NB; b++) { start[b] = a; a += hist[b]; }
+    }
+    __syncthreads();
+    // position of sorted index sg (slowest first).  Work queue: the queue hands out positions in
+    // order.  Static schedule: workgroup b, wave w, half h works on position b cpb + 2 w + h; the
+    // sorted PAIRS are dealt across the workgroups (pair 0 -> wave 0 of workgroup 0, pair 1 -> wave 0
+    // of workgroup 1, ...), so every CU gets its share of the slow waves.
+    const int cpb = prm.order_cpb;
+    const int nb = cpb > 0 ? (n + cpb - 1) / cpb : 1;
+    const int cells_last = cpb > 0 ? n - (nb - 1) * cpb : 0;
+    auto position = [&](int sg) {
+        if (cpb <= 0) return sg;
+        int w = 0, rowstart = 0;
+        for (;; w++) {
+            const int cw = min(2, max(0, cells_last - 2 * w));
+            const int rowsize = 2 * (nb - 1) + cw;
+            if (sg < rowstart + rowsize || 2 * (w + 1) >= cpb) break;
+            rowstart += rowsize;
+        }
+        const int idx = sg - rowstart;
+        const int b = idx < 2 * (nb - 1) ? (idx >> 1) : nb - 1;
+        const int h = idx < 2 * (nb - 1) ? (idx & 1) : idx - 2 * (nb - 1);
+        return b * cpb + 2 * w + h;
+    };
+    for (int t0 = 0; t0 < n; t0 += NT) {
+        const int i = t0 + tid;
+        const int b = i < n ? prm.perm_key[base + i] : -1;
+        int rank = 0;
+#pragma unroll
+        for (int bb = 0; bb < NB; bb++) {
+            const unsigned long long m = __ballot(b == bb);
+            if (lane == 0) wcnt[wave][bb] = __popcll(m);
+            if (b == bb) rank = __popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (i < n) {
+            int o = start[b] + rank;
+            for (int w = 0; w < wave; w++) o += wcnt[w][b];
+            prm.perm[base + position(o)] = base + i;
+        }
+        __syncthreads();
+        if (tid < NB) {
+            int a = 0;
+            for (int w = 0; w < NW; w++) a += wcnt[w][tid];
+            start[tid] += a;
+        }
+        __syncthreads();
+    }
+}
+
 // One workgroup (16 waves) per series.  Every theta-independent statistic is a wave-parallel
 // strided sum over t followed by a shuffle reduction (fixed summation tree: deterministic);
 // statistics are dealt round-robin to the waves.
 __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
+    if (prm.perm && (int)blockIdx.x >= prm.n_series) {      // the second half of the grid orders the cells
+        order_cells(prm, (int)blockIdx.x - prm.n_series);
+        return;
+    }
     const int s = blockIdx.x;
     const int T = prm.T, p = prm.p, q = prm.q, PP = prm.PP, QQ = prm.QQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -220,19 +327,27 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
     if (sc.status == 0) {
         // chunk-transposed images (layout: em_scan_impl.h) of y and the WHITENED inputs
         // (ldsr_device.h mstep_update_white; built after the factors): the K = 1+PP+QQ values of a step in
-        // pairs, pair m of step j of virtual lane l at [((j*KP + m)*NL + l)*2 + {0,1}]; 0 where
-        // missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
+        // pairs (em_scan_impl.h img_off: pair m of step j of virtual lane l at [((j*KH + m)*NL + l)*2 + {0,1}],
+        // the odd value of an odd K paired over two steps behind them); 0 where missing / beyond the chunk / padding.  img: the scan kernel's (64 W lanes); img2: the pair
         // kernel's (32 lanes, its own chunk length).
         // toff: the image covers the steps [toff, T) (the pair kernel's LEAD form), else 0
         auto build_image = [&](double *im, int L, int NL, int toff) {
-            const int K = 1 + PP + QQ, KP = (K + 1) / 2;
+            const int K = 1 + PP + QQ, KH = K / 2;
             const int Tt = T - toff;
             const int nl = (Tt + L - 1) / L, rp = Tt - nl * (L - 1);
-            for (int e = tid; e < NL * L * KP * 2; e += NT) {
-                const int h = e & 1, l = (e >> 1) % NL, jm = (e >> 1) / NL, j = jm / KP, m = jm - j * KP;
-                const int i = 2 * m + h;
+            const int n_pair = NL * L * KH * 2;                       // the full pairs, then the odd values' block
+            const int n_all = (int)img_doubles(L, NL, PP, QQ);
+            for (int e = tid; e < n_all; e += NT) {
+                int i, j, l;
+                if (e < n_pair) {
+                    const int h = e & 1, jm = (e >> 1) / NL, m = jm % KH;
+                    l = (e >> 1) % NL; j = jm / KH; i = 2 * m + h;
+                } else {                                              // value K-1 of steps 2 jj and 2 jj + 1
+                    const int r = e - n_pair;
+                    l = (r >> 1) % NL; j = 2 * ((r >> 1) / NL) + (r & 1); i = K - 1;
+                }
                 const int t = toff + l * (L - 1) + min(l, rp) + j;
-                const bool ok = l < nl && (j < L - 1 || l < rp);
+                const bool ok = l < nl && j < L && (j < L - 1 || l < rp);
                 double val = 0.0;
                 if (ok) {
                     if (i == 0) {
@@ -241,11 +356,11 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
                     } else if (i <= PP) {             // whitened inputs: row k of Lu^{-1} u_t / Lv^{-1} v_t
                         const int k = i - 1;
                         if (u && k < p && t < T - 1)
-                            for (int j = 0; j <= k; j++) val = fma(sc.Lu_inv[k * LDSR_MAXPQ + j], u[(long)t * p + j], val);
+                            for (int j_ = 0; j_ <= k; j_++) val = fma(sc.Lu_inv[k * LDSR_MAXPQ + j_], u[(long)t * p + j_], val);
                     } else if (i < K) {
                         const int k = i - 1 - PP;
                         if (v && k < q)
-                            for (int j = 0; j <= k; j++) val = fma(sc.Lv_inv[k * LDSR_MAXPQ + j], v[(long)t * q + j], val);
+                            for (int j_ = 0; j_ <= k; j_++) val = fma(sc.Lv_inv[k * LDSR_MAXPQ + j_], v[(long)t * q + j_], val);
                     }
                 }
                 im[e] = val;
@@ -698,7 +813,7 @@ void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len) {
 }
 
 hipError_t launch_series_prep(const PrepParams &prm, int n_series, hipStream_t stream) {
-    hipLaunchKernelGGL(series_prep_kernel, dim3(n_series), dim3(1024), 0, stream, prm);
+    hipLaunchKernelGGL(series_prep_kernel, dim3(prm.perm ? 2 * n_series : n_series), dim3(1024), 0, stream, prm);
     return hipGetLastError();
 }
 

@@ -401,6 +401,12 @@ static bool lead_enabled() {
     return on;
 }
 
+// LDSR_STEADY_ORDER=0: the steady form takes the cells in the caller's order (A/B runs)
+static bool order_enabled() {
+    static const bool on = [] { const char *e = getenv("LDSR_STEADY_ORDER"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool pair_enabled() {
     static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
     return on;
@@ -430,11 +436,16 @@ static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32, int le
 }
 
 struct WsLayout {
-    size_t sc, yp, yz, up, vp, img, img2, img3, blk, soc, queue, scratch, total;
+    size_t sc, yp, yz, up, vp, img, img2, img3, blk, soc, queue, perm, perm_key, scratch, total;
     long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
     long img2_stride;                  // pair kernel's image (0 = none)
     long img3_stride;                  // ... and its lead image
     int max_blocks, img_L, img_NL, img2_L, img2_NL = 32, lead = 0;
+    // cell order of the pair kernel's steady form (series_prep orders when order_on): set per launch
+    bool order_on = false;
+    int order_cpb = 0, order_ntr = 0;
+    const double *order_theta0 = nullptr;
+    const int *order_off = nullptr;     // device copy of the cell offsets (behind the block table)
 };
 
 static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, int n_cells,
@@ -464,9 +475,14 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
     if (PP <= 8 && QQ <= 8 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 4);    // the pair family's smallest workgroup
     L.max_blocks = n_cells / cpb + n_series + 1;
-    L.blk = o; o = align256(o + sizeof(int) * 3 * (size_t)L.max_blocks);
+    // (block table, then the device copy of the cell offsets for series_prep's cell ordering)
+    L.blk = o; o = align256(o + sizeof(int) * (3 * (size_t)L.max_blocks + (size_t)n_series + 1));
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
     L.queue = o; o = align256(o + sizeof(int) * (size_t)n_series);
+    // cell order of the pair kernel's steady form (two cells per wave, narrow inputs): position -> cell, and the keys
+    const bool may_order = PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL;
+    L.perm = o; o = align256(o + (may_order ? sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1) : 0));
+    L.perm_key = o; o = align256(o + (may_order ? sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1) : 0));
     L.scratch_stride = ((long)n_cells + 63) / 64 * 64;
     L.scratch = o;
     if (algo == LDSR_ALGO_SERIAL) o = align256(o + sizeof(double) * 2 * (size_t)T * L.scratch_stride);
@@ -634,6 +650,13 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.lead = L.lead;
     pp.img3 = (L.lead > 0 && L.img3_stride) ? (double *)(ws + L.img3) : nullptr;
     pp.img3_stride = L.img3_stride;
+    pp.n_series = n_series;
+    pp.perm = L.order_on ? (int *)(ws + L.perm) : nullptr;
+    pp.perm_key = (int *)(ws + L.perm_key);
+    pp.cell_off = L.order_off;
+    pp.theta0 = L.order_theta0;
+    pp.order_cpb = L.order_cpb;
+    pp.order_ntr = L.order_ntr;
     HIPCHK(launch_series_prep(pp, n_series, stream));
     return LDSR_OK;
 }
@@ -749,22 +772,12 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         return fail(LDSR_EINVAL, "LDSR_ALGO_PAIR needs 65 <= T <= 1024, p, q <= 4 and a series image that leaves room for eight waves per CU (ldsr_em_plan tells)");
     if (algo == LDSR_ALGO_QUAD && !em_pair_supported(Te, PP, QQ, 16, lead > 0))
         return fail(LDSR_EINVAL, "LDSR_ALGO_QUAD needs 65 <= T <= 512, p, q <= 4 (ldsr_em_plan tells)");
-    // Wide inputs (padded p or q = 8), every series fully observed: the scan kernel's plan and image,
-    // the pair family's body with its steady-state sweeps, ONE cell per wave (LDSR_WAVE64=0: off)
-    static const bool wave64_on = [] { const char *e = getenv("LDSR_WAVE64"); return !(e && atoi(e) == 0); }();
-    const bool wave64 = algo == LDSR_ALGO_SCAN && was_auto && dense_hint == 1 && wave64_on && pair_enabled() &&
-                        em_pair_supported(T, PP, QQ, 64);
-    if (wave64) lpc = 64;
-    const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD || wave64;      // the pair family's body
+    const bool cpw = algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD;                // the pair family's body
     if (algo_used) *algo_used = algo;
-    const int cpb = wave64 ? em_pair_cells_per_block(T, PP, QQ, 64)
-                           : cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
+    const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
-    if (wave64) {    // (reads the scan kernel's image: same layout)
-        L.img2_stride = 0;
-        L.img3_stride = 0;
-    } else if (cpw) {       // the image of the member that runs (the room is for the largest)
+    if (cpw) {       // the image of the member that runs (the room is for the largest)
         long sz = 0;
         em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz, lead > 0);
         L.img2_NL = lpc;
@@ -778,9 +791,6 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     if (((size_t)d_workspace & 255) != 0) return fail(LDSR_EINVAL, "workspace must be 256-byte aligned");
     HIPCHK(hipSetDevice(device));
     char *ws = (char *)d_workspace;
-
-    rc = prepare_series(stream, n_series, T, p, q, PP, QQ, d_y, d_u, d_v, shared_uv, ws, L);
-    if (rc) return rc;
 
     // block table: blocks never straddle a series.  Static mapping (serial kernel; scan kernel
     // when tol == 0, i.e. every cell runs exactly niter iterations): (series, first cell, n cells
@@ -809,7 +819,21 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     tab.insert(tab.end(), bc.begin(), bc.end());
     tab.insert(tab.end(), bn.begin(), bn.end());
     int *d_tab = (int *)(ws + L.blk);
+    // Steady form of the two-cells-per-wave kernel (fully observed series, chunks of >= 24 steps):
+    // series_prep also orders every series' cells by predicted slowness (em_pair_impl.h
+    // em_pair_body_steady); it reads the cell offsets from the device copy behind the block table.
+    const bool steady_launch = cpw && lpc == 32 && lead == 0 && pair_steady(L.img2_L, 32, PP, QQ) && order_enabled();
+    if (steady_launch) {
+        tab.insert(tab.end(), cell_offsets, cell_offsets + n_series + 1);
+        L.order_on = true;
+        L.order_cpb = use_queue ? 0 : cpb;
+        L.order_ntr = L.img2_L - 1;
+        L.order_theta0 = d_theta0;
+        L.order_off = d_tab + 3 * n_blocks;
+    }
     rc = stage_h2d_async(device, stream, d_tab, tab.data(), sizeof(int) * tab.size());
+    if (rc) return rc;
+    rc = prepare_series(stream, n_series, T, p, q, PP, QQ, d_y, d_u, d_v, shared_uv, ws, L);
     if (rc) return rc;
 
     EmParams prm;
@@ -827,7 +851,6 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.img_stride = L.img_stride;
     prm.img2 = L.img2_stride ? (const double *)(ws + L.img2) : nullptr;
     prm.img2_stride = L.img2_stride;
-    if (wave64) { prm.img2 = prm.img; prm.img2_stride = L.img_stride; }
     prm.lead = cpw ? lead : 0;
     prm.img3 = (cpw && lead > 0) ? (const double *)(ws + L.img3) : nullptr;
     prm.img3_stride = L.img3_stride;
@@ -842,6 +865,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.theta = d_theta; prm.lik = d_lik; prm.liks = d_liks;
     prm.n_iter = d_n_iter; prm.status = d_status;
     prm.queue = (int *)(ws + L.queue);
+    prm.perm = steady_launch ? (const int *)(ws + L.perm) : nullptr;
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
     int slot;
@@ -1326,7 +1350,10 @@ static void make_slices(std::vector<Slice> &sl, int n_devices, const int *device
         S.g_lo.assign((size_t)n_series, 0);
         for (int s = 0; s < n_series; s++) {
             const long long a = cell_offsets[s], ns = cell_offsets[s + 1] - cell_offsets[s];
-            const int lo = (int)(a + ns * d / n_devices), hi = (int)(a + ns * (d + 1) / n_devices);
+            // part (d + s) mod n_devices of series s: the remainders of restart counts the device count
+            // does not divide rotate over the devices (ldsr_amd/shard.py rank_slice is the same rule)
+            const long long k = (d + s) % n_devices;
+            const int lo = (int)(a + ns * k / n_devices), hi = (int)(a + ns * (k + 1) / n_devices);
             S.g_lo[(size_t)s] = lo;
             S.off[(size_t)s + 1] = S.off[(size_t)s] + (hi - lo);
         }

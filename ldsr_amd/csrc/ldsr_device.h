@@ -308,6 +308,7 @@ struct EmParams {
     const SeriesConst *sc;   // [n_series]
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
+    const int *perm;         // pair kernel, steady form: position -> cell (slowest cells first), or null
     const double *theta0;    // [n_cells][6+p+q]
     double *theta, *lik, *liks;
     int *n_iter, *status;
@@ -325,6 +326,20 @@ struct EmParams {
 // thread): bypasses the GPU caches, costs one PCIe round trip -- hence only every 64 iterations.
 __device__ __forceinline__ int ldsr_poll_abort(const int *flag) {
     return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Series-image layout of the scan / pair kernels (described in em_scan_impl.h)
+__host__ __device__ constexpr int img_values(int PP, int QQ) { return 1 + PP + QQ; }
+// doubles of an image of NL virtual lanes with chunks of L steps
+__host__ __device__ constexpr long img_doubles(int L, int NL, int PP, int QQ) {
+    const int K = img_values(PP, QQ);
+    return (long)NL * 2 * (L * (K / 2) + (K & 1) * ((L + 1) / 2));
+}
+// offset (doubles) of value i of step j, to which the lane adds 2 l
+__host__ __device__ constexpr int img_off(int j, int i, int K, int NL, int L) {
+    const int KH = K / 2;
+    return i < 2 * KH ? ((j * KH + (i >> 1)) * NL) * 2 + (i & 1)
+                      : (L * KH + (j >> 1)) * NL * 2 + (j & 1);
 }
 
 #define LDSR_LOG_2PI 1.8378770664093454835606594728112

@@ -20,6 +20,16 @@ struct PrepParams {
     long img3_stride;
     SeriesConst *sc;
     int *queue;               // [n_series] work-queue heads, reset to 0 here
+    // Cell order of the pair kernel's steady form (em_pair_impl.h em_pair_body_steady): n_series more
+    // workgroups sort every series' cells by the predicted number of steps its variance recursion needs
+    // to settle at theta0, slowest first -- perm[position] = cell.  Null: no ordering.
+    int *perm;                // [n_cells]
+    int *perm_key;            // [n_cells] scratch (the cells' buckets)
+    const int *cell_off;      // [n_series + 1] device copy of the cell offsets
+    const double *theta0;     // [n_cells][6 + p + q]
+    int n_series;
+    int order_cpb;            // static schedule: cells per workgroup (positions are dealt across the workgroups); 0 = work queue
+    int order_ntr;            // steps of the transient block (L - 1)
 };
 
 struct SmoothParams {

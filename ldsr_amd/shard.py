@@ -2,7 +2,10 @@
 
 Cells never communicate during EM (the reference runs them as independent foreach tasks handed
 to whichever worker is idle, R/LDS_reconstruction.R:46), so the grid is cut with no data-path
-collective: rank r owns the r-th of `world` contiguous parts of EVERY series' restarts.  Series
+collective: every rank owns one of `world` contiguous parts of EVERY series' restarts -- of series
+s the part (r + s) mod world, so the remainders of restart counts that `world` does not divide
+(the reference's defaults: 50 restarts, cvLDS 20) rotate over the ranks instead of piling up on the
+same ones (50 restarts x 48 series at 8 ranks: 300 cells each; without the rotation 288..336).  Series
 differ a lot in iterations to converge (BASELINE config 5: 34 k to 130 k E-steps per series), while
 the restarts of one series are statistically alike -- so equal shares of every series are equal
 shares of the work (max / mean E-steps per rank 1.004 / 1.007 / 1.012 at 2 / 4 / 8 ranks on config 5,
@@ -14,10 +17,13 @@ library cuts the same way for callers without torch.distributed (make_slices, ld
 import numpy as np
 
 
-def rank_slice(n_cells, world, rank):
-    """Contiguous range [lo, hi): the rank's part of ONE series' n_cells restarts."""
-    lo = n_cells * rank // world
-    hi = n_cells * (rank + 1) // world
+def rank_slice(n_cells, world, rank, series=0):
+    """Contiguous range [lo, hi): the rank's part of ONE series' n_cells restarts -- part
+    (rank + series) mod world of the `world` contiguous parts (the same rule as make_slices in
+    ldsr_api.hip)."""
+    k = (rank + series) % world
+    lo = n_cells * k // world
+    hi = n_cells * (k + 1) // world
     return lo, hi
 
 
@@ -29,7 +35,7 @@ def rank_stripes(cell_offsets, world, rank):
     g_lo = np.empty(S, dtype=np.int64)
     loc = np.zeros(S + 1, dtype=np.int32)
     for s in range(S):
-        lo, hi = rank_slice(int(off[s + 1] - off[s]), world, rank)
+        lo, hi = rank_slice(int(off[s + 1] - off[s]), world, rank, s)
         g_lo[s] = off[s] + lo
         loc[s + 1] = loc[s] + (hi - lo)
     return g_lo, loc

@@ -345,7 +345,9 @@ def test_singular_series_and_bad_shapes(eng):
         assert np.all(r["status"] == 2) and np.all(np.isnan(r["theta"])) and np.all(r["n_iter"] == 0)
         assert np.all(np.isnan(r["liks"]))
     # shapes outside the kernel: explicit PAIR is an error, AUTO goes elsewhere
-    assert _plan_name(600, 1, 2, 0.0, QUAD)[0] == -1 and _plan_name(512, 3, 3, 0.0, QUAD)[0] == -1
+    assert _plan_name(600, 1, 2, 0.0, QUAD)[0] == -1 and _plan_name(513, 3, 3, 0.0, QUAD)[0] == -1
+    # (an odd number of values per step no longer pads the image: nine values at L = 32 fit since round 4)
+    assert _plan_name(512, 3, 3, 0.0, QUAD) == (QUAD, "em_pair_kernel<4, 4, 32, 16, false, false>")
     for (T2, p2, q2) in ((64, 1, 2), (1025, 1, 2), (1000, 5, 2), (1000, 1, 5), (1000, 1, 4), (900, 4, 4)):
         assert _plan_name(T2, p2, q2, 0.0, PAIR)[0] == -1
         a, name = _plan_name(T2, p2, q2, 0.0, 0)

@@ -105,8 +105,30 @@ def test_stripes_cover_grid_exactly():
                 assert loc[0] == 0 and loc[-1] == shard.stripe_index(off, world, r).size
                 for s in range(len(off) - 1):         # a contiguous part of the series, inside it
                     assert off[s] <= g_lo[s] <= g_lo[s] + loc[s + 1] - loc[s] <= off[s + 1]
+    # rank 1 of 2: part (1 + s) % 2 of series s -- the second half of series 0 and 2, the first of series 1
     g_lo, loc = shard.rank_stripes([0, 5, 7, 13], 2, 1)
-    assert g_lo.tolist() == [2, 6, 10] and loc.tolist() == [0, 3, 4, 7]
+    assert g_lo.tolist() == [2, 5, 10] and loc.tolist() == [0, 3, 4, 7]
+
+
+def test_striped_cut_balances_the_reference_restart_counts():
+    """The reference's own restart counts (LDS_reconstruction: 50, cvLDS: 20, small runs: 5, one
+    restart per series) are not multiples of the device count.  Without the per-series rotation of
+    the part index the remainders pile up on the same ranks (8 ranks: 50 -> 6,6,6,7,6,6,6,7 per
+    series = 1.12 x the mean, 5 restarts leave three ranks idle, 1 restart x 48 series puts every cell
+    on the last rank); with it every rank gets its share to within one cell per series block."""
+    from ldsr_amd import shard
+    S = 48
+    for R in (50, 20, 5, 1):
+        off = np.arange(S + 1) * R
+        for world in (2, 4, 8):
+            n = [shard.stripe_index(off, world, r).size for r in range(world)]
+            assert sum(n) == S * R
+            assert max(n) * world / sum(n) <= 1.05, (R, world, n)
+    # a ragged grid: restart counts differ by series
+    off = np.concatenate([[0], np.cumsum([50, 7, 20, 1, 5, 33, 50, 2, 9, 50, 20, 11] * 4)])
+    for world in (4, 8):
+        n = [shard.stripe_index(off, world, r).size for r in range(world)]
+        assert max(n) * world / sum(n) <= 1.08, (world, n)
 
 
 def test_striped_cut_balances_converged_config5():
