@@ -28,6 +28,8 @@ Prints ONE JSON line on rank 0; see the task contract for the fields.  Extra obj
                 numbers (HBM bytes per launch, VALU instructions) come from committed rocprofv3
                 --pmc passes of this same command (profiles/pmc_summary.json) and are emitted
                 only when an entry for this workload AND this kernel instantiation exists.
+  host_entry    the same workload through ldsr_em_batch (host pointers, PCIe in/out) -- what the R shim
+                calls; reported beside `value`, never as it
   cpu_baseline  the CPU oracle (a port of src/EM.cpp, not RcppArmadillo) on the host cores
   verified      a 64-cell sample of the last timed launch against the CPU oracle (outside the
                 timed region): identical iteration counts, theta and lik within the parity bar
@@ -241,6 +243,42 @@ def verify_sample(job, p, q, niter, tol, n_sample=64):
             "bar": "|d| <= 1e-6 |ref| + 1e-9 on every theta entry and on lik", "ok": ok}
 
 
+def host_entry_rate(L, job, T, p, q, niter, tol, algo, units_rank, steps=10, warmup=2):
+    """The same workload through the HOST-POINTER entry the R shim calls (ldsr_em_batch: operands in
+    host memory, one pinned->device copy in, kernels, one copy back, one synchronisation; the lead /
+    fully-observed fact is found from y by the library) -- timed outside the headline loop, reported
+    next to it, never `value`.  Plain ctypes on preallocated arrays: no Python wrapper in the loop."""
+    from ldsr_amd import _lib
+    Y = np.ascontiguousarray(job.d_y.cpu().numpy())
+    U = np.ascontiguousarray(job.d_u.cpu().numpy())
+    V = np.ascontiguousarray(job.d_v.cpu().numpy())
+    th0 = np.ascontiguousarray(job.d_th0.cpu().numpy())
+    n, P = th0.shape
+    th = np.empty_like(th0)
+    lik = np.empty(n)
+    nit = np.empty(n, np.int32)
+    st = np.empty(n, np.int32)
+    off = (C.c_int * (job.S + 1))(*[int(x) for x in job.loc_off])
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def call():
+        _lib.check(L.ldsr_em_batch(job.local_rank, job.S, T, p, q, ptr(Y), ptr(U), ptr(V), job.shared_uv,
+                                   off, ptr(th0), niter, tol, algo, ptr(th), ptr(lik), ptr(nit), ptr(st),
+                                   None))
+    for _ in range(warmup):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    dt = (time.perf_counter() - t0) / steps
+    units = int(nit.sum())
+    return {"entry": "ldsr_em_batch (host pointers: PCIe in and out, lead found from y by the library)",
+            "ms_per_call": dt * 1e3, "value": units / dt, "unit": "restart*EM-iter/s", "steps": steps,
+            "units_per_call": units, "same_units_as_device_entry": units == units_rank,
+            "bytes_in": int(Y.nbytes + U.nbytes + V.nbytes + th0.nbytes),
+            "bytes_out": int(th.nbytes + lik.nbytes + nit.nbytes + st.nbytes)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` invoked plainly: start the N ranks as a CHILD
     `python -m torch.distributed.run` (this parent never imports torch or touches the GPU, and
@@ -263,6 +301,7 @@ class Job:
     def __init__(self, L, torch, dev, local_rank, prob, T, p, q, niter, tol, algo):
         from ldsr_amd import _lib
         Y, U, V, self.shared_uv, loc_off, th0, self.n_global = prob
+        self.local_rank = local_rank
         self.loc_off = np.asarray(loc_off, dtype=np.int64)
         self.S, self.cells = Y.shape[0], th0.shape[0]
         self.d_y = torch.from_numpy(Y).to(dev)          # [S][T]
@@ -323,6 +362,8 @@ def main():
                     help="headline split of a single-series workload over the ranks (default weak: "
                          "the per-GPU configuration of BASELINE.json; strong: its restarts / N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-entry", action="store_true",
+                    help="skip the host-pointer-entry leg (ldsr_em_batch, PCIe-inclusive; reported beside value)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of a 64-cell sample of the last timed launch")
     args = ap.parse_args()
@@ -473,6 +514,14 @@ def main():
                 roof["fp64_executed_frac"] = roof["fp64_executed_tflops"] / FP64_VALU_PEAK_TFLOPS
             if pmc.get("valu_active_per_wave_cycle") is not None:
                 roof["valu_busy_frac"] = 2.0 * pmc["valu_active_per_wave_cycle"]   # two waves per SIMD
+            if pmc.get("sustained_clock_ghz"):
+                # `peak` assumes the 2.4 GHz boost clock; under fp64 load the chip holds less
+                # (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the committed PMC pass): the same
+                # achieved rate against the peak AT THAT CLOCK separates clock from code
+                clk = pmc["sustained_clock_ghz"]
+                roof["sustained_clock_ghz"] = clk
+                roof["peak_at_sustained_clock"] = FP64_VALU_PEAK_TFLOPS * clk / (CLOCK_HZ / 1e9)
+                roof["frac_at_sustained_clock"] = tflops / roof["peak_at_sustained_clock"]
         out = {
             "metric": "restart x EM-iteration / s (T=%d, p=%d, q=%d)" % (T, p, q),
             "value": value, "unit": "restart*EM-iter/s", "n_gpus": world, "steps": args.steps,
@@ -498,6 +547,10 @@ def main():
             if not out["verified"]["ok"]:
                 print(json.dumps(out), flush=True)
                 sys.exit("bench.py: the timed launch does not match the CPU oracle")
+        if world == 1 and not args.no_host_entry:
+            he = host_entry_rate(L, job, T, p, q, niter, args.tol, args.algo, units_rank)
+            he["vs_device_resident"] = he["value"] / (units_rank * args.steps / dt)
+            out["host_entry"] = he
         if world == 1 and not args.no_cpu_baseline:
             Y, U, V = (job.d_y.cpu().numpy(), job.d_u.cpu().numpy(), job.d_v.cpu().numpy())
             out["cpu_baseline"] = cpu_baseline(p, q, niter, Y, U, V, seed=1)

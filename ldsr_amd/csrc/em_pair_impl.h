@@ -438,10 +438,8 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 
     while (__any(alive)) {
         SCAN_TICK(7)       // M-step, stop rule, loop
-        const double A = th.A, C = th.C, Q = th.Q, R = th.R;
-        const double A2 = A * A, C2 = C * C;
-        const double rR = fast_rcp(R);
-        const double C2R = C2 * rR, alpha = fma(Q, C2R, A2);
+        const double A = th.A, Q = th.Q;
+        const double A2 = A * A;
 
         // ------------------------------------------------ LEAD: the all-missing first `lead` steps
         // Over unobserved steps K_t = 0 (src/EM.cpp:82-84): Xp_{t+1} = A Xp_t + B u_t and
@@ -788,30 +786,295 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
 // With every y_t observed the variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t:
 // src/EM.cpp:76,86,88,100) is the data-independent Riccati recursion, which reaches its fixed point
 // geometrically -- within 31 steps for 99.2 % of the (cell, iteration) pairs of BASELINE config 2 (a numpy
-// replay of the bench grid; 16 % of the cells fail at theta0, 0.4 % after ten iterations).  The first
-// NTR = L-1 steps of the series (the chunk of lane 0 without its predicated step) are done ONE STEP PER
-// LANE (a 2x2 scan of the variance step matrices, an affine scan of the means, the reference's expressions
-// from the exact entry state); lane 31 is no transient step, its "entry state" is the state at t = NTR and
-// what it evaluates there are the steady constants K, 1/Sigma, Vu, J, h, log Sigma.  Verdict, per CELL:
-// one more step leaves Vp unchanged to 2^-48, every Sigma of the block is positive, J^2 < 0.8.  Cells that
-// pass run the STEADY SWEEPS on t >= NTR: only the mean recursions (affine, constant multipliers), 19 fp64
-// operations per step where the generic sweeps take 50, no h_t strip, the variance sums in closed form.
-// Cells that fail (slow Riccati convergence: A near 1 with a small gain, mostly in the first EM
-// iterations) take the generic sweeps for that iteration.
+// replay of the bench grid; 16 % of the cells fail at theta0, 0.4 % after ten iterations, ONE cell of the
+// 4096 for 31 iterations).  The first NTR = L-1 steps of the series (the chunk of lane 0 without its
+// predicated step) are done ONE STEP PER LANE (a 2x2 scan of the variance step matrices, an affine scan
+// of the means, the reference's expressions from the exact entry state); lane 31 is no transient step,
+// its "entry state" is the state at t = NTR and what it evaluates there are the steady constants K,
+// 1/Sigma, Vu, J, h, log Sigma.  Verdict, per CELL: one more step leaves Vp unchanged to 2^-48, every
+// Sigma of the block is positive, J^2 < 0.8.  Cells that pass run the STEADY SWEEPS on t >= NTR: only the
+// mean recursions (affine, constant multipliers), 19 fp64 operations per step where the generic sweeps
+// take 50, no h_t strip, the variance sums in closed form.  Cells that fail (slow Riccati convergence: A
+// near 1 with a small gain, mostly in the first EM iterations) take the generic sweeps for that iteration.
 //
 // TWO LOOPS, ONE PER FORM (round 4).  Round 3 ran the generic sweeps as a `noinline` call inside the steady
-// loop: ~300 scratch accesses around every call (52 MB of spill traffic per launch), and a wave with one
-// slow and one fast cell paid transient block + steady sweeps + call, ~4x a steady iteration.  Now the wave
-// is a two-state machine.  S loop: steady iterations for all its cells; left as soon as a cell fails the
-// verdict.  G loop: generic iterations (pair_generic_sweeps inlined, nothing of the steady form live) for
-// the cells that fail, while a cell that passes WAITS -- its iteration count simply does not advance;
-// left when no cell fails any more.  Each loop body holds one form only, so each gets the register
-// allocation the stand-alone kernels have (no call, no scratch), and a slow iteration costs one generic
-// iteration.  Which form a cell's iteration takes is decided by the cell's own theta (var_block is the
-// same explicit-fma code in both loops), so its arithmetic never depends on its wave partner or on the
-// order in which cells are handed out -- only the time at which it is computed does.
-// series_prep orders the cells of a series by predicted slowness (EmParams.perm, slowest first, dealt
-// across the workgroups): slow cells share waves with slow cells, and the work queue hands them out first.
+// loop, once per slow cell and iteration: ~300 scratch accesses around every call (52 MB of spill traffic
+// per launch), and a wave with one slow and one fast cell paid transient block + steady sweeps + call.
+// Now the wave is a two-state machine.  S loop (here, inlined in the kernel): steady iterations for all
+// its cells; left as soon as a cell fails the verdict.  G phase (pair_steady_g_phase, a REAL function:
+// its own register allocation, entered once per slow episode, not once per iteration): generic
+// iterations for the cells that fail, while a cell that passes WAITS -- its iteration count simply does
+// not advance; left when no cell of the wave fails any more.  (Both loops inlined in one function body
+// compiled -- and ran, parity-green -- but the allocator then spills ~150 VGPRs in whichever loop it
+// considers colder, although each loop alone fits: 38 k cycles per generic iteration against 22 k.)
+// Which form a cell's iteration takes is decided by the cell's own theta (pair_var_block is the same
+// explicit-fma code on both sides), so its arithmetic never depends on its wave partner or on the order in
+// which cells are handed out -- only the time at which it is computed does.  series_prep orders the cells of
+// a series by predicted slowness (EmParams.perm, slowest first, dealt across the workgroups): slow cells
+// share waves with slow cells, and the work queue hands them out first.
+
+// what the iteration epilogue needs of EmParams (launch-uniform)
+struct PairEnv {
+    int T, p, q, has_u, has_v, niter, liks_nanfill, n_obs;
+    double tol;
+    const SeriesConst *sc;      // this series' constants
+    int *queue_s;               // this series' work-queue head
+    const int *perm;            // position -> cell, or null
+    const double *theta0;
+    double *theta, *lik, *liks;
+    int *n_iter, *status;
+    const int *abort;
+};
+// ... and the state of this lane's cell carried from iteration to iteration
+template <int PP, int QQ>
+struct PairCarry {
+    Theta<PP, QQ> th;
+    double lik, lik1, lik2;
+    int it, cell, wit;
+    bool alive;
+#ifdef LDSR_SCAN_TIMING
+    unsigned long long tick_[10], last_, real0_;
+#endif
+};
+#ifdef LDSR_SCAN_TIMING
+#define PAIR_TICK_REFS auto &tick_ = cs.tick_; auto &last_ = cs.last_;
+#else
+#define PAIR_TICK_REFS
+#endif
+
+__device__ __forceinline__ int pair_cell_at(const PairEnv &E, int c0, int pos) { return E.perm ? E.perm[c0 + pos] : c0 + pos; }
+
+__device__ __forceinline__ void pair_mark_interrupted(const PairEnv &E, int cell) {
+    const int P = 6 + E.p + E.q;
+    for (int k = 0; k < P; k++) E.theta[(long)cell * P + k] = NAN;
+    if (E.liks && E.liks_nanfill)
+        for (int i = 0; i < E.niter; i++) E.liks[(long)cell * E.niter + i] = NAN;
+    E.n_iter[cell] = 0;
+    E.lik[cell] = NAN;
+    E.status[cell] = 3;
+}
+
+// ---- variance side of the transient block, and the verdict.  Explicit fma / mul only: the S loop and the
+// G phase each compile a copy and must decide alike.  (a) inclusive scan of the 2x2 step matrices
+// [[alpha, Q],[C2R, 1]] (one and the same for every step: scaled by an exact power of two so that
+// max(alpha, 1) c is in [0.5, 1), as the generic dense F1 does; identity beyond step NTR-1), then
+// Vp = (p00 V1 + p01) / (p10 V1 + p11) of the lane before; (b) the reference's expressions, as in F2.
+struct PairVarBlk { double Vp, sg, r0, K, Vu, AVu, J, Vp1; bool st; };
+template <int L>
+__device__ __forceinline__ PairVarBlk pair_var_block(double V1, double A, double C, double Q, double R, bool live,
+                                                     int vl, int hbase, bool shape_ok) {
+    constexpr int LPC = 32, NTR = L - 1;
+    PairVarBlk b;
+    const double A2 = A * A, C2 = C * C;
+    const double C2R = C2 * fast_rcp(R), alpha = fma(Q, C2R, A2);
+    const bool trl = vl < NTR;
+    double Vp;
+    {
+        const double mxs = fmax(alpha, 1.0);
+        const int ke = -__builtin_amdgcn_frexp_exp(mxs);
+        const double cs = __builtin_amdgcn_ldexp(1.0, ke);
+        double p00 = trl ? alpha * cs : 1.0, p01 = trl ? Q * cs : 0.0;
+        double p10 = trl ? C2R * cs : 0.0, p11 = trl ? cs : 1.0;
+#define VSCAN_ROUND(Q00, Q01, Q10, Q11)                                                      \
+        {                                                                            \
+            const double q00 = Q00, q01 = Q01, q10 = Q10, q11 = Q11;                 \
+            const double r00 = fma(p00, q00, p01 * q10), r01 = fma(p00, q01, p01 * q11); \
+            const double r10 = fma(p10, q00, p11 * q10), r11 = fma(p10, q01, p11 * q11); \
+            p00 = r00; p01 = r01; p10 = r10; p11 = r11;                              \
+        }
+#define VSCAN_SHR(n) VSCAN_ROUND(dpp1<DPP_ROW_SHR(n)>(p00), dppz<DPP_ROW_SHR(n)>(p01), dppz<DPP_ROW_SHR(n)>(p10), dpp1<DPP_ROW_SHR(n)>(p11))
+        VSCAN_SHR(1) VSCAN_SHR(2) VSCAN_SHR(4)
+        {   // exact power-of-two rescale (projective coordinates are scale free)
+            const double m = fmax(fmax(fabs(p00), fabs(p01)), fmax(fabs(p10), fabs(p11)));
+            const int e2 = 1 - __builtin_amdgcn_frexp_exp(m);
+            p00 = __builtin_amdgcn_ldexp(p00, e2); p01 = __builtin_amdgcn_ldexp(p01, e2);
+            p10 = __builtin_amdgcn_ldexp(p10, e2); p11 = __builtin_amdgcn_ldexp(p11, e2);
+        }
+        VSCAN_SHR(8)
+        VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
+                    (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
+#undef VSCAN_SHR
+#undef VSCAN_ROUND
+        double n_e = fma(p00, V1, p01), d_e = fma(p10, V1, p11);
+        n_e = dppd<DPP_WAVE_SHR1, 0xF>(V1, n_e);
+        d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
+        if (vl == 0) { n_e = V1; d_e = 1.0; }
+        Vp = n_e * fast_rcp(d_e);                            // entering step vl (vl >= NTR: t = NTR)
+    }
+    const double sg = fma(C2, Vp, R);
+    const double r0 = fast_rcp(sg);
+    const double w = Vp * r0;
+    b.K = C * w;                                             // src/EM.cpp:86
+    b.Vu = R * w;                                            // :88
+    b.Vp1 = fma(A2, b.Vu, Q);                                // :76
+    b.AVu = A * b.Vu;
+    b.J = b.AVu * fast_rcp(b.Vp1);                           // :100
+    b.Vp = Vp; b.sg = sg; b.r0 = r0;
+    // fixed point reached, and every Sigma of the block positive (a negative one is the generic
+    // sweeps' business: lik = NaN); J^2 < 0.8, which a converged Riccati recursion implies unless V1
+    // happens to be the fixed point itself, lets the closed-form variance sums drop J^(2(T-NTR))
+    const double dV = b.Vp1 - Vp;
+    const bool conv = fabs(dV) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && b.J * b.J < 0.8;
+    const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
+    const unsigned long long cvm = __ballot(conv);
+    constexpr unsigned long long CELL = (1ull << LPC) - 1ull;
+    const unsigned long long hm = (okm >> hbase) & CELL, hc = (cvm >> hbase) & CELL;
+    b.st = live && hm == CELL && ((hc >> (LPC - 1)) & 1ull) != 0ull && shape_ok;
+    return b;
+}
+
+// ---- the rest of an iteration for the halves in `active` (the cells whose sweeps just ran): one
+// reduction per half, likelihood, stop rule, M-step; a cell that stops stores its result and -- work
+// queue -- its half pulls the next one.  The other halves keep their state untouched.
+template <int PP, int QQ, bool QUEUE>
+__device__ __forceinline__ void pair_steady_finish(const PairEnv &E, PairCarry<PP, QQ> &cs, const PairSweepOut<PP, QQ> &o,
+                                                   double addTx1x, double addPall, bool active, int lane, int c0,
+                                                   int nc, int lastLane) {
+    constexpr int LPC = 32;
+    PAIR_TICK_REFS
+    const int vl = lane & 31, hbase = lane & 32;
+    const int P = 6 + E.p + E.q;
+    Sums<PP, QQ> S;
+    {
+        constexpr int NB = 5;
+        constexpr int NR = NB + QQ + 2 * PP;
+        double red[NR];
+        red[0] = o.aSyx; red[1] = o.aTx1x; red[2] = o.aPall; red[3] = o.likq; red[4] = o.lsp;
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) red[NB + q_] = o.aSxv[q_];
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = o.aTx1u[p_]; red[NB + QQ + PP + p_] = o.aTux[p_]; }
+        // recursive halving over the half's 32 lanes (em_scan_impl.h), then every lane fetches
+        // the totals from their home lanes of its own half
+        red_rounds<NR, LPC / 2>(red, lane);
+        {
+            const double tt = red[0];
+#pragma unroll
+            for (int i = 0; i < NR; i++) red[i] = shfl_d(tt, hbase | red_home(i, NR, LPC));
+        }
+        S.X0 = shfl_d(o.X0v, hbase);               // :218
+        S.V0 = shfl_d(o.V0v, hbase);               // :219
+        const double termLast = shfl_d(o.tLv, hbase | lastLane);
+        red[1] += addTx1x; red[2] += addPall;      // (steady form: the closed-form variance sums; else 0)
+        const double term0 = fma(S.X0, S.X0, S.V0);
+        const unsigned long long negm = __ballot(o.sneg < 0);
+        const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
+        S.Syx = red[0]; S.Tx1x = red[1];
+        S.Sxx = red[2];
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) S.Sxv[q_] = red[NB + q_];
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) { S.Tx1u[p_] = red[NB + QQ + p_]; S.Tux[p_] = red[NB + QQ + PP + p_]; }
+        S.Txx = red[2] - termLast;
+        S.Tx1x1 = red[2] - term0;
+        if (active) {
+            cs.lik2 = cs.lik1;
+            cs.lik1 = cs.lik;
+            cs.lik = (-0.5 * E.n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / E.n_obs;   // :113-124
+            if (neg) cs.lik = NAN;
+        }
+    }
+    SCAN_TICK(8)       // reduction, likelihood
+    int abort_now = 0;
+    if (E.abort && ((++cs.wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
+        abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(E.abort) : 0);
+    if (active && E.liks && vl == 0) E.liks[(long)cs.cell * E.niter + cs.it] = cs.lik;
+    if (active) cs.it++;
+    bool stop = active && cs.it >= E.niter;
+    if (active && cs.it >= 3 && fabs(cs.lik - cs.lik1) < E.tol && fabs(cs.lik1 - cs.lik2) < E.tol) stop = true;   // :272
+    if (cs.alive && abort_now) stop = true;       // (a waiting cell stops too)
+    if (cs.alive && stop) {
+        // theta stays the one that produced this fit (:276-279)
+        white_out(cs.th, (SeriesConstK)E.sc);
+        if (vl == 0) {
+            store_theta(cs.th, E.theta + (long)cs.cell * P, E.p, E.q);
+            if (E.liks && E.liks_nanfill)
+                for (int i = cs.it; i < E.niter; i++) E.liks[(long)cs.cell * E.niter + i] = NAN;
+            E.n_iter[cs.cell] = cs.it;
+            E.lik[cs.cell] = cs.lik;
+            E.status[cs.cell] = (abort_now && cs.it < E.niter) ? 3 : (isfinite(cs.lik) ? 0 : 1);
+#ifdef LDSR_SCAN_TIMING
+            tick_[9] = __builtin_amdgcn_s_memrealtime() - cs.real0_;      // -> shader clock = cycles / this x 100 MHz
+            if (E.liks && E.niter >= 10)
+                for (int k_ = 0; k_ < 10; k_++) E.liks[(long)cs.cell * E.niter + k_] = (double)tick_[k_];
+#endif
+        }
+        cs.alive = false;
+        if constexpr (QUEUE) {
+            if (abort_now) {
+                // drain the queue: what it still holds is marked, not computed (an
+                // LDSR_EINTERRUPTED return never leaves stale numbers that look like results)
+                for (int pulls = 0; pulls <= nc; pulls++) {
+                    int kn = 0;
+                    if (vl == 0) kn = atomicAdd(E.queue_s, 1);
+                    kn = __shfl(kn, hbase, 64);
+                    if (kn >= nc) break;
+                    if (vl == 0) pair_mark_interrupted(E, pair_cell_at(E, c0, kn));
+                }
+            } else {
+                int kn = 0;
+                if (vl == 0) kn = atomicAdd(E.queue_s, 1);
+                kn = __shfl(kn, hbase, 64);
+                if (kn < nc) {
+                    cs.alive = true;
+                    cs.cell = pair_cell_at(E, c0, kn);
+                    load_theta(cs.th, E.theta0 + (long)cs.cell * P, E.p, E.q, E.has_u, E.has_v);
+                    white_in(cs.th, (SeriesConstK)E.sc);
+                    cs.it = 0;
+                    cs.lik = NAN; cs.lik1 = NAN; cs.lik2 = NAN;
+                }
+            }
+        }
+    } else if (active) {
+        mstep_update_white<PP, QQ>(cs.th, S, (SeriesConstK)E.sc, E.T);
+    }
+}
+
+// ---- G phase: generic iterations for the halves whose cell fails the verdict (`slow`, from the S loop's
+// verdict on entry: at least one iteration runs), until no cell of the wave fails.  A real function: the
+// generic sweeps keep 244 VGPRs busy, and entered once per slow episode the ~250 scratch accesses of
+// the call (callee-saved registers, the caller's live state) are spread over its iterations.  The
+// launch-uniform arguments arrive in VGPRs like any other and are made scalar again first.
+template <int PP, int QQ, int L, bool QUEUE>
+__device__ __attribute__((noinline)) PairCarry<PP, QQ> pair_steady_g_phase(PairEnv Ev, PairCarry<PP, QQ> cs, bool slow,
+                                                                           int c0, int nc) {
+    constexpr int LPC = 32;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    PAIR_TICK_REFS
+    auto ui = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto up = [&](auto *ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (decltype(ptr))(((unsigned long long)hi << 32) | lo);
+    };
+    PairEnv E;
+    E.T = ui(Ev.T); E.p = ui(Ev.p); E.q = ui(Ev.q); E.has_u = ui(Ev.has_u); E.has_v = ui(Ev.has_v);
+    E.niter = ui(Ev.niter); E.liks_nanfill = ui(Ev.liks_nanfill); E.n_obs = ui(Ev.n_obs);
+    E.tol = uniform_d(Ev.tol);
+    E.sc = up(Ev.sc); E.queue_s = up(Ev.queue_s); E.perm = up(Ev.perm); E.theta0 = up(Ev.theta0);
+    E.theta = up(Ev.theta); E.lik = up(Ev.lik); E.liks = up(Ev.liks); E.n_iter = up(Ev.n_iter);
+    E.status = up(Ev.status); E.abort = up(Ev.abort);
+    c0 = ui(c0); nc = ui(nc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vl = lane & 31, hbase = lane & 32;
+    const int T = E.T;
+    const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+    const bool shape_ok = rp >= 1 && nl > 1;
+    const double *ys = smem;
+    double *hs = smem + pair_image_doubles(L, PP, QQ, LPC) + (long)wave * pair_strip_doubles(L) + lane;
+    do {
+        SCAN_TICK(7)
+        PairSweepOut<PP, QQ> o;
+        pair_generic_sweeps<PP, QQ, L, LPC, true>(o, cs.th, ys, hs, 0u, lane, nl, rp, cs.th.mu1, cs.th.V1);
+        SCAN_TICK(6)       // the generic sweeps
+        pair_steady_finish<PP, QQ, QUEUE>(E, cs, o, 0.0, 0.0, slow, lane, c0, nc, nl - 1);
+        const PairVarBlk vb = pair_var_block<L>(cs.th.V1, cs.th.A, cs.th.C, cs.th.Q, cs.th.R, cs.alive, vl, hbase, shape_ok);
+        slow = cs.alive && !vb.st;
+    } while (__any(slow));
+    return cs;
+}
+
 template <int PP, int QQ, int L, bool QUEUE>
 __device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const double *ys, double *hs,
                                                     const double *tri, int s, int c0, int nc, int lane,
@@ -820,7 +1083,7 @@ __device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const d
     constexpr int KP = scan_pairs(PP, QQ), KV = img_values(PP, QQ);
     constexpr int NTR = L - 1;
     static_assert(NTR < LPC, "the last lane of the cell is the template, not a transient step");
-    const int half = lane >> 5, vl = lane & 31, hbase = lane & 32;
+    const int vl = lane & 31, hbase = lane & 32;
     auto val = [&](int j, int i) -> double { return ys[img_off(j, i, KV, LPC, L) + vl * 2]; };
     // all K values of step j of this lane (ds_read_b128 each pair)
     auto ldw = [&](int j, double (&w)[2 * KP]) {
@@ -833,230 +1096,64 @@ __device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const d
     constexpr int PF2 = LDSR_STEADY_PF2;
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
-    const SeriesConst *__restrict__ sc = prm.sc + s;
-    const int n_obs = sc->n_obs;
+    PairEnv E;
+    E.T = T; E.p = prm.p; E.q = prm.q; E.has_u = prm.has_u; E.has_v = prm.has_v;
+    E.niter = prm.niter; E.liks_nanfill = prm.liks_nanfill; E.tol = prm.tol;
+    E.sc = prm.sc + s; E.n_obs = E.sc->n_obs;
+    E.queue_s = prm.queue + s; E.perm = prm.perm; E.theta0 = prm.theta0;
+    E.theta = prm.theta; E.lik = prm.lik; E.liks = prm.liks; E.n_iter = prm.n_iter; E.status = prm.status;
+    E.abort = prm.abort;
     const int nl = (T + L - 1) / L;          // active lanes of a half
     const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
     const bool act = vl < nl;
     const bool tail = vl < rp;
     const int lastLane = nl - 1;             // (within the half) owner of step T-1
     const bool shape_ok = rp >= 1 && nl > 1; // lane 0 owns L steps: the block ends on a chunk boundary
-    const int *__restrict__ perm = prm.perm; // position -> cell (series_prep: slowest first), or null
 
     // this half's cell
-    int k = QUEUE ? 0 : 2 * wave + half;
+    PairCarry<PP, QQ> cs;
+    int k = QUEUE ? 0 : 2 * wave + (lane >> 5);
     if constexpr (QUEUE) {
-        if (vl == 0) k = atomicAdd(prm.queue + s, 1);
+        if (vl == 0) k = atomicAdd(E.queue_s, 1);
         k = __shfl(k, hbase, 64);
     }
-    bool alive = k < nc;
-    auto cell_at = [&](int pos) { return perm ? perm[c0 + pos] : c0 + pos; };
-    int cell = cell_at(alive ? k : 0);
-    Theta<PP, QQ> th;
-    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
-    double lik = NAN, lik1 = NAN, lik2 = NAN;
-    int it = 0;
-    int wit = 0;             // wave-uniform iteration count (interrupt poll)
-    bool aborted = false;    // the host raised the interrupt flag
+    cs.alive = k < nc;
+    cs.cell = pair_cell_at(E, c0, cs.alive ? k : 0);
+    load_theta(cs.th, prm.theta0 + (long)cs.cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    white_in(cs.th, (SeriesConstK)E.sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
+    cs.lik = NAN; cs.lik1 = NAN; cs.lik2 = NAN;
+    cs.it = 0;
+    cs.wit = 0;              // wave-uniform iteration count (interrupt poll)
 #ifdef LDSR_SCAN_TIMING
-    unsigned long long tick_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long last_ = __builtin_readcyclecounter();
-    const unsigned long long real0_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    for (int k_ = 0; k_ < 10; k_++) cs.tick_[k_] = 0;
+    cs.last_ = __builtin_readcyclecounter();
+    cs.real0_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
+    PAIR_TICK_REFS
+    Theta<PP, QQ> &th = cs.th;
 
-    // what the sweeps of either form leave in every lane
-    double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
-    double addPall = 0.0, addTx1x = 0.0;    // steady form: closed-form variance sums of the steady region
-    int sneg = 0;
-    double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0;
-    double aSxv[QQ], aTx1u[PP], aTux[PP];
-    auto zero_sums = [&]() {
-        aSyx = 0.0; aTx1x = 0.0; aPall = 0.0;
-#pragma unroll
-        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
-#pragma unroll
-        for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
-    };
-
-    // ---- variance side of the transient block, and the verdict.  Explicit fma / mul only: the two loops
-    // each inline a copy and must decide alike.  (a) inclusive scan of the 2x2 step matrices
-    // [[alpha, Q],[C2R, 1]] (one and the same for every step: scaled by an exact power of two so that
-    // max(alpha, 1) c is in [0.5, 1), as the generic dense F1 does; identity beyond step NTR-1), then
-    // Vp = (p00 V1 + p01) / (p10 V1 + p11) of the lane before; (b) the reference's expressions, as in F2.
-    struct VarBlk { double Vp, sg, r0, K, Vu, AVu, J, Vp1; bool st; };
-    auto var_block = [&](double V1, double A, double C, double Q, double R, bool live) -> VarBlk {
-        VarBlk b;
-        const double A2 = A * A, C2 = C * C;
-        const double C2R = C2 * fast_rcp(R), alpha = fma(Q, C2R, A2);
-        const bool trl = vl < NTR;
-        double Vp;
-        {
-            const double mxs = fmax(alpha, 1.0);
-            const int ke = -__builtin_amdgcn_frexp_exp(mxs);
-            const double cs = __builtin_amdgcn_ldexp(1.0, ke);
-            double p00 = trl ? alpha * cs : 1.0, p01 = trl ? Q * cs : 0.0;
-            double p10 = trl ? C2R * cs : 0.0, p11 = trl ? cs : 1.0;
-#define VSCAN_ROUND(Q00, Q01, Q10, Q11)                                                      \
-            {                                                                            \
-                const double q00 = Q00, q01 = Q01, q10 = Q10, q11 = Q11;                 \
-                const double r00 = fma(p00, q00, p01 * q10), r01 = fma(p00, q01, p01 * q11); \
-                const double r10 = fma(p10, q00, p11 * q10), r11 = fma(p10, q01, p11 * q11); \
-                p00 = r00; p01 = r01; p10 = r10; p11 = r11;                              \
-            }
-#define VSCAN_SHR(n) VSCAN_ROUND(dpp1<DPP_ROW_SHR(n)>(p00), dppz<DPP_ROW_SHR(n)>(p01), dppz<DPP_ROW_SHR(n)>(p10), dpp1<DPP_ROW_SHR(n)>(p11))
-            VSCAN_SHR(1) VSCAN_SHR(2) VSCAN_SHR(4)
-            {   // exact power-of-two rescale (projective coordinates are scale free)
-                const double m = fmax(fmax(fabs(p00), fabs(p01)), fmax(fabs(p10), fabs(p11)));
-                const int e2 = 1 - __builtin_amdgcn_frexp_exp(m);
-                p00 = __builtin_amdgcn_ldexp(p00, e2); p01 = __builtin_amdgcn_ldexp(p01, e2);
-                p10 = __builtin_amdgcn_ldexp(p10, e2); p11 = __builtin_amdgcn_ldexp(p11, e2);
-            }
-            VSCAN_SHR(8)
-            VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
-                        (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
-#undef VSCAN_SHR
-#undef VSCAN_ROUND
-            double n_e = fma(p00, V1, p01), d_e = fma(p10, V1, p11);
-            n_e = dppd<DPP_WAVE_SHR1, 0xF>(V1, n_e);
-            d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
-            if (vl == 0) { n_e = V1; d_e = 1.0; }
-            Vp = n_e * fast_rcp(d_e);                            // entering step vl (vl >= NTR: t = NTR)
-        }
-        const double sg = fma(C2, Vp, R);
-        const double r0 = fast_rcp(sg);
-        const double w = Vp * r0;
-        b.K = C * w;                                             // src/EM.cpp:86
-        b.Vu = R * w;                                            // :88
-        b.Vp1 = fma(A2, b.Vu, Q);                                // :76
-        b.AVu = A * b.Vu;
-        b.J = b.AVu * fast_rcp(b.Vp1);                           // :100
-        b.Vp = Vp; b.sg = sg; b.r0 = r0;
-        // fixed point reached, and every Sigma of the block positive (a negative one is the generic
-        // sweeps' business: lik = NaN); J^2 < 0.8, which a converged Riccati recursion implies unless V1
-        // happens to be the fixed point itself, lets the closed-form variance sums drop J^(2(T-NTR))
-        const double dV = b.Vp1 - Vp;
-        const bool conv = fabs(dV) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && b.J * b.J < 0.8;
-        const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
-        const unsigned long long cvm = __ballot(conv);
-        constexpr unsigned long long CELL = (1ull << LPC) - 1ull;
-        const unsigned long long hm = (okm >> hbase) & CELL, hc = (cvm >> hbase) & CELL;
-        b.st = live && hm == CELL && ((hc >> (LPC - 1)) & 1ull) != 0ull && shape_ok;
-        return b;
-    };
-
-    // ---- the rest of an iteration for the halves in `active` (the cells whose sweeps just ran): one
-    // reduction per half, likelihood, stop rule, M-step; a cell that stops stores its result and -- work
-    // queue -- its half pulls the next one.  The other halves keep their state untouched.
-    auto finish_iteration = [&](bool active, bool steady_form) {
-        Sums<PP, QQ> S;
-        {
-            constexpr int NB = 5;
-            constexpr int NR = NB + QQ + 2 * PP;
-            double red[NR];
-            red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
-#pragma unroll
-            for (int q_ = 0; q_ < QQ; q_++) red[NB + q_] = aSxv[q_];
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) { red[NB + QQ + p_] = aTx1u[p_]; red[NB + QQ + PP + p_] = aTux[p_]; }
-            // recursive halving over the half's 32 lanes (em_scan_impl.h), then every lane fetches
-            // the totals from their home lanes of its own half
-            red_rounds<NR, LPC / 2>(red, lane);
-            {
-                const double tt = red[0];
-#pragma unroll
-                for (int i = 0; i < NR; i++) red[i] = shfl_d(tt, hbase | red_home(i, NR, LPC));
-            }
-            S.X0 = shfl_d(X0v, hbase);               // :218
-            S.V0 = shfl_d(V0v, hbase);               // :219
-            const double termLast = shfl_d(tLv, hbase | lastLane);
-            if (steady_form) { red[1] += addTx1x; red[2] += addPall; }
-            const double term0 = fma(S.X0, S.X0, S.V0);
-            const unsigned long long negm = __ballot(sneg < 0);
-            const bool neg = ((negm >> hbase) & ((1ull << LPC) - 1ull)) != 0;   // log of a negative Sigma
-            S.Syx = red[0]; S.Tx1x = red[1];
-            S.Sxx = red[2];
-#pragma unroll
-            for (int q_ = 0; q_ < QQ; q_++) S.Sxv[q_] = red[NB + q_];
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) { S.Tx1u[p_] = red[NB + QQ + p_]; S.Tux[p_] = red[NB + QQ + PP + p_]; }
-            S.Txx = red[2] - termLast;
-            S.Tx1x1 = red[2] - term0;
-            if (active) {
-                lik2 = lik1;
-                lik1 = lik;
-                lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;   // :113-124
-                if (neg) lik = NAN;
-            }
-        }
-        SCAN_TICK(8)       // reduction, likelihood
-        int abort_now = 0;
-        if (prm.abort && ((++wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
-            abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
-        if (abort_now) aborted = true;
-        if (active && prm.liks && vl == 0) prm.liks[(long)cell * prm.niter + it] = lik;
-        if (active) it++;
-        bool stop = active && it >= prm.niter;
-        if (active && it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;   // :272
-        if (alive && abort_now) stop = true;       // (a waiting cell stops too)
-        if (alive && stop) {
-            // theta stays the one that produced this fit (:276-279)
-            white_out(th, (SeriesConstK)sc);
-            if (vl == 0) {
-                store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
-                if (prm.liks && prm.liks_nanfill)
-                    for (int i = it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
-                prm.n_iter[cell] = it;
-                prm.lik[cell] = lik;
-                prm.status[cell] = (abort_now && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
-#ifdef LDSR_SCAN_TIMING
-                tick_[9] = __builtin_amdgcn_s_memrealtime() - real0_;      // -> shader clock = cycles / this x 100 MHz
-                if (prm.liks && prm.niter >= 10)
-                    for (int k_ = 0; k_ < 10; k_++) prm.liks[(long)cell * prm.niter + k_] = (double)tick_[k_];
-#endif
-            }
-            alive = false;
-            if constexpr (QUEUE) {
-                if (abort_now) {
-                    // drain the queue: what it still holds is marked, not computed (an
-                    // LDSR_EINTERRUPTED return never leaves stale numbers that look like results)
-                    for (int pulls = 0; pulls <= nc; pulls++) {
-                        int kn = 0;
-                        if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
-                        kn = __shfl(kn, hbase, 64);
-                        if (kn >= nc) break;
-                        if (vl == 0) mark_cell_interrupted(prm, cell_at(kn));
-                    }
-                } else {
-                    int kn = 0;
-                    if (vl == 0) kn = atomicAdd(prm.queue + s, 1);
-                    kn = __shfl(kn, hbase, 64);
-                    if (kn < nc) {
-                        alive = true;
-                        cell = cell_at(kn);
-                        load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-                        white_in(th, (SeriesConstK)sc);
-                        it = 0;
-                        lik = NAN; lik1 = NAN; lik2 = NAN;
-                    }
-                }
-            }
-        } else if (active) {
-            mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
-        }
-    };
-
-    bool go_g = false;       // the S loop met a cell that fails the verdict
-    bool slow = false;       // G loop: this half's cell takes the generic sweeps in this iteration
-    while (__any(alive)) {
+    while (__any(cs.alive)) {
         // ================================================================= S loop: steady iterations
-        while (__any(alive)) {
+        bool slow = false;
+        while (__any(cs.alive)) {
             SCAN_TICK(7)       // M-step, stop rule, loop
-            const double A = th.A, C = th.C, Q = th.Q;
-            const VarBlk vb = var_block(th.V1, A, C, Q, th.R, alive);
+            const double A = th.A, C = th.C;
+            const PairVarBlk vb = pair_var_block<L>(th.V1, A, C, th.Q, th.R, cs.alive, vl, hbase, shape_ok);
             const bool st = vb.st;
-            slow = alive && !st;
-            if (__builtin_expect(__any(slow), 0)) { go_g = true; break; }
+            slow = cs.alive && !st;
+            if (__builtin_expect(__any(slow), 0)) break;
+            // what the sweeps leave in every lane
+            double likq = 0.0, lsp = 0.0, tLv = 0.0, X0v = 0.0, V0v = 0.0;
+            double addPall = 0.0, addTx1x = 0.0;    // closed-form variance sums of the steady region
+            double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0;
+            double aSxv[QQ], aTx1u[PP], aTux[PP];
+            auto zero_sums = [&]() {
+                aSyx = 0.0; aTx1x = 0.0; aPall = 0.0;
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+            };
             // ---- mean side of the transient block: Xp_{t+1} = A (1 - K_t C) Xp_t + (A K_t e_t + B u_t) is
             // affine with the gains just found: inclusive scan over the lanes, then the reference's
             // expressions from the exact entry state
@@ -1095,7 +1192,6 @@ __device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const d
             const int src = hbase | (LPC - 1);
             const double cK = shfl_d(K, src), cJ = shfl_d(J, src), cr = shfl_d(r0, src), cVu = shfl_d(Vu, src);
             const double ch = shfl_d(trH, src), clg = shfl_d(lg, src), X_tr = shfl_d(Xp, src);
-            likq = 0.0; lsp = 0.0; tLv = 0.0; X0v = 0.0; V0v = 0.0; addPall = 0.0; addTx1x = 0.0; sneg = 0;
 
             SCAN_TICK(0)       // iteration constants, transient block, verdict
             if (st) {          // (idle halves -- no cell left -- skip the sweeps)
@@ -1320,29 +1416,18 @@ __device__ __forceinline__ void em_pair_body_steady(const EmParams &prm, const d
                 zero_sums();       // (an idle half: nothing ran)
             }
             SCAN_TICK(5)       // closed-form variance sums, transient block backwards
-            finish_iteration(st, true);
+            PairSweepOut<PP, QQ> o;
+            o.aSyx = aSyx; o.aTx1x = aTx1x; o.aPall = aPall; o.aSxx = 0.0;
+            o.likq = likq; o.lsp = lsp; o.tLv = tLv; o.X0v = X0v; o.V0v = V0v; o.sneg = 0;
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) o.aSxv[q_] = aSxv[q_];
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { o.aTx1u[p_] = aTx1u[p_]; o.aTux[p_] = aTux[p_]; }
+            pair_steady_finish<PP, QQ, QUEUE>(E, cs, o, addTx1x, addPall, st, lane, c0, nc, lastLane);
         }
-        if (__builtin_expect(!go_g, 1)) break;
-        go_g = false;
-        // ================================================================= G loop: generic iterations
-        // (entered with `slow` from the S loop's verdict: at least one iteration runs)
-        do {
-            SCAN_TICK(7)
-            {
-                PairSweepOut<PP, QQ> o;
-                pair_generic_sweeps<PP, QQ, L, LPC, true>(o, th, ys, hs, 0u, lane, nl, rp, th.mu1, th.V1);
-                aSyx = o.aSyx; aTx1x = o.aTx1x; aPall = o.aPall;
-                likq = o.likq; lsp = o.lsp; tLv = o.tLv; X0v = o.X0v; V0v = o.V0v; sneg = o.sneg;
-#pragma unroll
-                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = o.aSxv[q_];
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = o.aTx1u[p_]; aTux[p_] = o.aTux[p_]; }
-            }
-            SCAN_TICK(6)       // the generic sweeps
-            finish_iteration(slow, false);
-            const VarBlk vb = var_block(th.V1, th.A, th.C, th.Q, th.R, alive);
-            slow = alive && !vb.st;
-        } while (__any(slow));
+        if (__builtin_expect(!__any(slow), 1)) break;      // every cell of the wave is done
+        // ================================================================= G phase: generic iterations
+        cs = pair_steady_g_phase<PP, QQ, L, QUEUE>(E, cs, slow, c0, nc);
     }
 }
 

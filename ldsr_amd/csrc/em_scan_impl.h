@@ -481,6 +481,9 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp, int &wit) {
     constexpr int NL = 64 * W;
+    // (the cell index is the same in every lane of the wave group: say so, or its 64-bit form for the
+    // result addresses sits in a VGPR pair across the whole EM loop -- the config-3 kernel spilled it)
+    cell = __builtin_amdgcn_readfirstlane(cell);
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
     const int vl = wv * 64 + lane;            // virtual lane

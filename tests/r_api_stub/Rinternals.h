@@ -29,6 +29,8 @@ SEXP Rf_allocMatrix(unsigned int, int, int);
 double *REAL(SEXP);
 int *INTEGER(SEXP);
 int Rf_isReal(SEXP);
+int TYPEOF(SEXP);
+SEXP Rf_coerceVector(SEXP, unsigned int);
 int Rf_ncols(SEXP);
 int Rf_nrows(SEXP);
 int Rf_asInteger(SEXP);

@@ -89,6 +89,19 @@ double *REAL(SEXP s) { if (s->type != REALSXP) Rf_error("rmock: REAL() on a non-
 int *INTEGER(SEXP s) { if (s->type != INTSXP && s->type != LGLSXP) Rf_error("rmock: INTEGER() on a non-integer"); return (int *)s->data; }
 R_xlen_t Rf_xlength(SEXP s) { return s->len; }
 int Rf_isReal(SEXP s) { return s->type == REALSXP; }
+int TYPEOF(SEXP s) { return s->type; }
+/* integer / logical -> double, dim kept; NA_INTEGER (INT_MIN) -> NA_real_ (a NaN) */
+SEXP Rf_coerceVector(SEXP s, unsigned int type) {
+    if (type != REALSXP || (s->type != INTSXP && s->type != LGLSXP)) Rf_error("rmock: unsupported coerceVector");
+    SEXP r = Rf_allocVector(REALSXP, s->len);
+    r->nrow = s->nrow;
+    r->ncol = s->ncol;
+    for (R_xlen_t i = 0; i < s->len; i++) {
+        const int v = ((int *)s->data)[i];
+        ((double *)r->data)[i] = v == (-2147483647 - 1) ? (0.0 / 0.0) : (double)v;
+    }
+    return r;
+}
 int Rf_ncols(SEXP s) { return s->nrow || s->ncol ? s->ncol : 1; }
 int Rf_nrows(SEXP s) { return s->nrow || s->ncol ? s->nrow : (int)s->len; }
 SEXP STRING_ELT(SEXP s, R_xlen_t i) { if (s->type != STRSXP || i >= s->len) Rf_error("rmock: bad STRING_ELT"); return ((SEXP *)s->data)[i]; }
@@ -185,6 +198,7 @@ typedef SEXP (*fn3)(SEXP, SEXP, SEXP);
 typedef SEXP (*fn4)(SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*fn5)(SEXP, SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*fn6)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+typedef SEXP (*fn7)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 
 /* .Call(name, args...): 0 = returned normally (*res set), 1 = Rf_error (message in
  * rmock_last_error()), 2 = no such routine / wrong arity.  Like R, an error unwinds the PROTECT
@@ -206,6 +220,7 @@ int rmock_call(const char *name, int nargs, SEXP *a, SEXP *res) {
     else if (nargs == 4) *res = ((fn4)d->fun)(a[0], a[1], a[2], a[3]);
     else if (nargs == 5) *res = ((fn5)d->fun)(a[0], a[1], a[2], a[3], a[4]);
     else if (nargs == 6) *res = ((fn6)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5]);
+    else if (nargs == 7) *res = ((fn7)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
     else { g_jmp_armed = 0; return 2; }
     g_jmp_armed = 0;
     return 0;
@@ -215,6 +230,11 @@ int rmock_call(const char *name, int nargs, SEXP *a, SEXP *res) {
 SEXP rmock_real_matrix(int nr, int nc, const double *src) {
     SEXP m = Rf_allocMatrix(REALSXP, nr, nc);
     memcpy(m->data, src, sizeof(double) * (size_t)nr * nc);
+    return m;
+}
+SEXP rmock_int_matrix(int nr, int nc, const int *src) {   /* an R integer matrix (1:10 and friends) */
+    SEXP m = Rf_allocMatrix(INTSXP, nr, nc);
+    memcpy(m->data, src, sizeof(int) * (size_t)nr * nc);
     return m;
 }
 SEXP rmock_scalar(int type, double v) {

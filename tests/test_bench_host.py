@@ -95,3 +95,59 @@ def test_pmc_entry_of_the_latest_round_counts():
         src = line["roofline"].get("pmc_source") or []
         assert src and all(("/%s_" % rounds[-1]) in s_ for s_ in src), (w, src)
         assert line["roofline"]["pmc_stale"] is False and line["verified"]["ok"] is True
+
+
+def test_sustained_clock_fields_of_the_roofline():
+    """roofline.peak assumes the 2.4 GHz boost clock; the chip holds less under fp64 load.  The
+    committed PMC passes carry the clock they saw (GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration) and
+    the bench line prices the same rate against the peak at THAT clock too."""
+    import json
+    import bench
+    entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["entries"]
+    latest = sorted({e["round"] for e in entries})[-1]
+    for e in entries:
+        if e["round"] == latest:
+            assert 1.5 < e["sustained_clock_ghz"] < 2.45, e["workload"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for field in ("sustained_clock_ghz", "frac_at_sustained_clock", "peak_at_sustained_clock", "host_entry"):
+        assert field in src
+    assert bench.FP64_VALU_PEAK_TFLOPS == 78.6 and bench.CLOCK_HZ == 2.4e9
+
+
+def test_host_entry_leg_builds_the_call_it_times(monkeypatch):
+    """The host_entry leg hands ldsr_em_batch the SAME operands as the device-resident job (host
+    copies of them) and reports units from the returned iteration counts -- checked here against a
+    stand-in library (no GPU): argument order, shapes and the reported fields."""
+    import types
+    import bench
+    Y, U, V, shared, off, th0, n_global = bench.build_problem("cfg5", "dense", 8, 3)
+    seen = {}
+
+    class FakeTensor:
+        def __init__(self, a):
+            self.a = a
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return self.a
+
+    job = types.SimpleNamespace(d_y=FakeTensor(Y), d_u=FakeTensor(U), d_v=FakeTensor(V), d_th0=FakeTensor(th0),
+                                S=Y.shape[0], loc_off=np.asarray(off), shared_uv=shared, local_rank=0)
+
+    def fake_em_batch(device, S, T, p, q, y, u, v, shared_uv, off_, th0_, niter, tol, algo, th, lik, nit, st, liks):
+        import ctypes as C
+        seen.update(S=S, T=T, p=p, q=q, shared=shared_uv, niter=niter, off=[off_[i] for i in range(S + 1)])
+        n = off_[S]
+        src = np.full(n, niter, np.int32)
+        C.memmove(nit, src.ctypes.data, 4 * n)
+        return 0
+    L = types.SimpleNamespace(ldsr_em_batch=fake_em_batch)
+    from ldsr_amd import _lib
+    monkeypatch.setattr(_lib, "check", lambda rc: None)
+    w = bench.WORKLOADS["cfg5"]
+    r = bench.host_entry_rate(L, job, w["T"], w["p"], w["q"], 7, 0.0, 0, th0.shape[0] * 7, steps=2, warmup=1)
+    assert seen["S"] == 48 and seen["T"] == 813 and seen["niter"] == 7 and seen["off"] == [int(x) for x in off]
+    assert r["units_per_call"] == th0.shape[0] * 7 and r["same_units_as_device_entry"] is True
+    assert r["value"] > 0 and r["bytes_in"] == Y.nbytes + U.nbytes + V.nbytes + th0.nbytes

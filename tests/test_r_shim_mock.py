@@ -28,6 +28,7 @@ class RMock:
                 ("rmock_interrupt_after", None, [ip]),
                 ("rmock_call", ip, [C.c_char_p, ip, C.POINTER(vp), C.POINTER(vp)]),
                 ("rmock_real_matrix", vp, [ip, ip, C.POINTER(C.c_double)]),
+                ("rmock_int_matrix", vp, [ip, ip, C.POINTER(C.c_int)]),
                 ("rmock_scalar", vp, [ip, C.c_double]), ("rmock_list", vp, [ip, ip]),
                 ("rmock_list_set", None, [vp, ip, C.c_char_p, vp]), ("rmock_type", ip, [vp]),
                 ("rmock_len", C.c_long, [vp]), ("rmock_nrow", ip, [vp]), ("rmock_ncol", ip, [vp]),
@@ -38,6 +39,9 @@ class RMock:
 
     def to_sexp(self, x):
         L = self.L
+        if isinstance(x, np.ndarray) and x.dtype.kind in "iub":   # an R integer / logical matrix
+            a = np.asfortranarray(np.atleast_2d(x), dtype=np.int32)
+            return L.rmock_int_matrix(a.shape[0], a.shape[1], a.ctypes.data_as(C.POINTER(C.c_int)))
         if isinstance(x, np.ndarray):                       # R matrices are column-major
             a = np.asfortranarray(np.atleast_2d(x), dtype=np.float64)
             return L.rmock_real_matrix(a.shape[0], a.shape[1], a.ctypes.data_as(C.POINTER(C.c_double)))
@@ -123,6 +127,7 @@ def test_registration_table_mirrors_the_reference(R):
     got = {R.L.rmock_routine_name(i).decode(): R.L.rmock_routine_nargs(i) for i in range(R.L.rmock_n_routines())}
     # arity of the entries they replace: src/RcppExports.cpp:132-143
     assert got == {"ldsrhip_LDS_EM_batch": 6, "ldsrhip_LDS_EM_grid": 6, "ldsrhip_LDS_EM": 6,
+                   "ldsrhip_LDS_EM_batch_raw": 6, "ldsrhip_LDS_EM_grid_raw": 6, "ldsrhip_LDS_EM_groups": 7,
                    "ldsrhip_Kalman_smoother": 5, "ldsrhip_propagate": 5, "ldsrhip_Mstep": 4}
 
 
@@ -139,7 +144,8 @@ def test_loaded_as_ldsr_it_registers_the_reference_table(R, refdata):
                      "_ldsr_NSE": 2, "_ldsr_nRMSE": 3, "_ldsr_corr": 2, "_ldsr_KGE": 2, "_ldsr_RE": 3}
         assert {k: v for k, v in got.items() if k.startswith("_ldsr_")} == reference
         assert {k: v for k, v in got.items() if not k.startswith("_ldsr_")} == {
-            "ldsrhip_LDS_EM_batch": 6, "ldsrhip_LDS_EM_grid": 6}
+            "ldsrhip_LDS_EM_batch": 6, "ldsrhip_LDS_EM_grid": 6, "ldsrhip_LDS_EM_batch_raw": 6,
+            "ldsrhip_LDS_EM_grid_raw": 6, "ldsrhip_LDS_EM_groups": 7}
         # the metric entries on fold 0 of the reference-held NPcv object
         from ldsr_amd import cv
         c = refdata["NPcv"]
@@ -154,6 +160,13 @@ def test_loaded_as_ldsr_it_registers_the_reference_table(R, refdata):
         assert R.call("_ldsr_RE", sim, obs, float(tr.mean()))[0] == pytest.approx(c["metrics_dist"]["RE"][0], rel=1e-10)
         with pytest.raises(RuntimeError, match="one \\(positive\\) length"):
             R.call("_ldsr_NSE", sim, obs[:5])
+        # integer / logical vectors are coerced like Rcpp's NumericVector parameters: NSE(1:10, obs)
+        ints = np.arange(1, sim.size + 1)
+        assert R.call("_ldsr_NSE", ints, obs)[0] == R.call("_ldsr_NSE", ints.astype(float), obs)[0]
+        assert R.call("_ldsr_corr", obs, ints % 2 == 0)[0] == pytest.approx(
+            np.corrcoef(obs, (ints % 2 == 0).astype(float))[0, 1], rel=1e-12)
+        with pytest.raises(RuntimeError, match="must be numeric"):
+            R.call("_ldsr_NSE", [1.0, 2.0], obs)
         assert L.rmock_protect_depth() == 0
     finally:
         assert L.rmock_init() == 1            # back to the side-car table for the other tests
@@ -176,6 +189,12 @@ def test_argument_errors_unwind_cleanly(R, p1case):
         R.call("ldsrhip_LDS_EM_batch", y, c["u"], c["v"], [th], 1, 1e-5)
     with pytest.raises(RuntimeError, match="one init list per column"):
         R.call("ldsrhip_LDS_EM_grid", np.stack([c["y"], c["y"]], axis=1), c["u"], c["v"], [[th]], 10, 1e-5)
+    with pytest.raises(RuntimeError, match="one element per ensemble member"):
+        R.call("ldsrhip_LDS_EM_groups", c["y"][:, None], [c["u"], c["u"]], [c["v"]], [[[th]]], 10, 1e-5, False)
+    with pytest.raises(RuntimeError, match="one init list per column of Y"):
+        R.call("ldsrhip_LDS_EM_groups", c["y"][:, None], [c["u"]], [c["v"]], [[[th], [th]]], 10, 1e-5, False)
+    with pytest.raises(RuntimeError, match="u must be numeric"):
+        R.call("ldsrhip_LDS_EM_batch", y, [1.0], c["v"], [th], 10, 1e-5)
     assert R.L.rmock_protect_depth() == 0
 
 
@@ -298,3 +317,66 @@ def test_user_interrupt_stops_a_running_launch(R, p1case):
     assert R.L.rmock_protect_depth() == 0
     m = R.call("ldsrhip_LDS_EM_batch", y[None, :], u, v, init[:8], 5, 0.0)   # the next call is unaffected
     assert m["liks"].shape == (5, 1)
+
+
+@pytest.mark.gpu
+def test_raw_trajectories_of_the_winners(R, npcase):
+    """use.raw / return.raw (R/LDS_reconstruction.R:279-281, :219-222): the batched entries also return
+    propagate(theta, u, v, y) of every winner -- here against the oracle's propagate (src/EM.cpp:295-356)
+    at the returned theta, fold by fold; integer-typed inputs are coerced on the way in."""
+    from oracle import oracle as O
+    from ldsr_amd import synth
+    c = npcase(1800)
+    T = c["y"].size
+    inst = np.nonzero(~np.isnan(c["y"]))[0]
+    folds = [inst[3:8], inst[20:26]]
+    Y = np.repeat(c["y"][None], 2, axis=0)
+    for f, z in enumerate(folds):
+        Y[f, z] = np.nan
+    th0 = synth.make_init_packed(3, 3, 12, seed=41)
+    inits = [[_theta_list(t, 3, 3) for t in th0[6 * f:6 * f + 6]] for f in range(2)]
+    plain = R.call("ldsrhip_LDS_EM_grid", np.ascontiguousarray(Y.T), c["u"], c["v"], inits, 60, 1e-5)
+    ms = R.call("ldsrhip_LDS_EM_grid_raw", np.ascontiguousarray(Y.T), c["u"], c["v"], inits, 60, 1e-5)
+    for f, (m, m0) in enumerate(zip(ms, plain)):
+        assert list(m) == ["theta", "fit", "liks", "lik", "index", "raw"] and list(m["raw"]) == ["X", "Y", "V", "lik"]
+        assert np.array_equal(m["fit"]["Y"], m0["fit"]["Y"]) and m["index"][0] == m0["index"][0]
+        th = np.concatenate([m["theta"][k].ravel() for k in ("A", "B", "C", "D", "Q", "R", "mu1", "V1")])
+        ref = O.propagate(th, c["u"], c["v"], Y[f])
+        for k in "XYV":
+            assert m["raw"][k].shape == (1, T)
+            assert np.allclose(m["raw"][k][0], np.asarray(ref[k]).ravel(), rtol=1e-9, atol=1e-12), (f, k)
+        assert m["raw"]["lik"][0] == pytest.approx(ref["lik"], rel=1e-9)
+    one = R.call("ldsrhip_LDS_EM_batch_raw", Y[:1], c["u"], c["v"], inits[0], 60, 1e-5)
+    assert list(one) == ["theta", "fit", "liks", "lik", "index", "raw", "all"]
+    assert np.array_equal(one["raw"]["Y"], ms[0]["raw"]["Y"])
+
+
+@pytest.mark.gpu
+def test_ensemble_members_in_one_call(R, npcase):
+    """LDS_reconstruction's ensemble loop (R/LDS_reconstruction.R:242-246) and cvLDS's folds x members
+    loop (:377-381) through ONE .Call: members differ in p and q (tests/testthat/test-ensemble.R:4-5: three
+    rows and two), one of them has no u at all; every (member, fold) model equals the grid entry run for
+    that member alone, bit for bit."""
+    from ldsr_amd import synth
+    c = npcase(1800)
+    inst = np.nonzero(~np.isnan(c["y"]))[0]
+    Y = np.repeat(c["y"][None], 2, axis=0)
+    Y[1, inst[5:12]] = np.nan
+    members = [(c["u"], c["v"], 3, 3), (c["u"][:2], c["v"][:2], 2, 2), (np.zeros((1, 1)), c["v"][:1], 1, 1)]
+    us, vs, inits = [], [], []
+    for k, (u, v, p, q) in enumerate(members):
+        th0 = synth.make_init_packed(p, q, 10, seed=50 + k)
+        us.append(u); vs.append(v)
+        inits.append([[_theta_list(t, p, q) for t in th0[5 * f:5 * f + 5]] for f in range(2)])
+    res = R.call("ldsrhip_LDS_EM_groups", np.ascontiguousarray(Y.T), us, vs, inits, 50, 1e-5, True)
+    assert len(res) == 3 and all(len(r) == 2 for r in res)
+    for k, (u, v, p, q) in enumerate(members):
+        alone = R.call("ldsrhip_LDS_EM_grid_raw", np.ascontiguousarray(Y.T), u, v, inits[k], 50, 1e-5)
+        for f in range(2):
+            a, b = res[k][f], alone[f]
+            assert a["index"][0] == b["index"][0] and a["lik"][0] == b["lik"][0]
+            for name in ("A", "B", "C", "D", "Q", "R", "mu1", "V1"):
+                assert np.array_equal(a["theta"][name], b["theta"][name])
+            assert a["theta"]["B"].shape == (1, p) and a["theta"]["D"].shape == (1, q)
+            assert np.array_equal(a["fit"]["Y"], b["fit"]["Y"]) and np.array_equal(a["raw"]["Y"], b["raw"]["Y"])
+    assert R.L.rmock_protect_depth() == 0

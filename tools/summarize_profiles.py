@@ -81,6 +81,15 @@ def main():
                 if kernel.split("<")[0] in r["Name"]:
                     rocprof_ms = float(r["AverageNs"]) / 1e6
         fetch, write = vals.get("FETCH_SIZE", 0.0), vals.get("WRITE_SIZE", 0.0)
+        # sustained clock while the EM kernel runs: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 /
+        # dispatch duration, of the timed dispatches of the sq2 pass (the first one is the warm-up)
+        clocks = []
+        for r in counter_rows(os.path.join(wdir, "sq2")):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and kernel.split("<")[0] in r["Kernel_Name"]:
+                dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                if dur > 0:
+                    clocks.append(float(r["Counter_Value"]) / 8.0 / dur)
+        clocks = clocks[1:] if len(clocks) > 1 else clocks
         e = {
             "round": rnd, "workload": w, "mask": "dense", "kernel": kernel,
             "niter": bench["config"]["niter"], "tol": bench["config"]["tol"],
@@ -107,6 +116,8 @@ def main():
             "wait_any_per_wave_cycle": (vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"])
             if vals.get("SQ_WAVE_CYCLES") else None,
             "lds_bank_conflict_cycles": vals.get("SQ_LDS_BANK_CONFLICT"),
+            "lds_idx_active_cycles": vals.get("SQ_LDS_IDX_ACTIVE"),
+            "sustained_clock_ghz": (sum(clocks) / len(clocks)) if clocks else None,
             "rocprof_kernel_ms": rocprof_ms,
             "bench_kernel_ms_same_command": under["roofline"]["kernel_ms"],
             "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
