@@ -259,11 +259,12 @@ def host_entry_rate(L, job, T, p, q, niter, tol, algo, units_rank, steps=10, war
     nit = np.empty(n, np.int32)
     st = np.empty(n, np.int32)
     off = (C.c_int * (job.S + 1))(*[int(x) for x in job.loc_off])
-    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
 
     def call():
-        _lib.check(L.ldsr_em_batch(job.local_rank, job.S, T, p, q, ptr(Y), ptr(U), ptr(V), job.shared_uv,
-                                   off, ptr(th0), niter, tol, algo, ptr(th), ptr(lik), ptr(nit), ptr(st),
+        _lib.check(L.ldsr_em_batch(job.local_rank, job.S, T, p, q, pd(Y), pd(U), pd(V), job.shared_uv,
+                                   off, pd(th0), niter, tol, algo, pd(th), pd(lik), pi(nit), pi(st),
                                    None))
     for _ in range(warmup):
         call()

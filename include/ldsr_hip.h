@@ -93,6 +93,10 @@ extern "C" {
 
 const char *ldsr_last_error(void);
 const char *ldsr_version(void);
+/* first 16 hex digits of the SHA-256 over the library's sources (every .hip, .h and .inc file of
+ * ldsr_amd/csrc, its Makefile and this header) it was built from: a caller that has the tree can tell a
+ * stale binary (ldsr_amd/_lib.py refuses one) */
+const char *ldsr_source_hash(void);
 int ldsr_device_count(void);
 void ldsr_shutdown(void);
 
@@ -191,6 +195,13 @@ int ldsr_em_batch_device_lead(int device, void *stream, int n_series, int T, int
                               size_t workspace_bytes, int lead_steps);
 int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int algo, int lead_steps,
                       char *buf, size_t len);
+/* The kernel one Kalman_smoother pass of this shape runs: LDSR_ALGO_SCAN and the name of the scan
+ * kernel's FIT form, or LDSR_ALGO_SERIAL (empty name) beyond its shapes; -1 for bad arguments. */
+int ldsr_smooth_plan(int T, int p, int q, char *buf, size_t len);
+/* Names (as rocprofv3 prints them, one per line) of every instantiation of the parallel-in-time kernel
+ * families compiled into this library; returns the buffer length needed.  The library is built to hold
+ * exactly what the plans above can return (tests/test_abi_and_host.py). */
+size_t ldsr_kernel_inventory(char *buf, size_t len);
 /* Name of the EM kernel of the most recent EM launch on `device` (what AUTO actually chose for that
  * launch's size and data); -1 if there was none. */
 int ldsr_last_em_kernel(int device, char *buf, size_t len);

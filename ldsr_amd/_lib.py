@@ -16,6 +16,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "ldsr_last_error": (C.c_char_p, []),
     "ldsr_version": (C.c_char_p, []),
+    "ldsr_source_hash": (C.c_char_p, []),
     "ldsr_device_count": (C.c_int, []),
     "ldsr_shutdown": (None, []),
     "ldsr_em_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
@@ -35,6 +36,8 @@ SIGNATURES = {
     "ldsr_em_batch_device_lead": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                             _vp, C.c_int, _ip, _vp, C.c_int, C.c_double, C.c_int, _vp,
                                             _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
+    "ldsr_smooth_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "ldsr_kernel_inventory": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "ldsr_last_em_kernel": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "ldsr_set_interrupt_callback": (C.c_int, [_vp, _vp]),
     "ldsr_em_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -78,6 +81,24 @@ class LdsrError(RuntimeError):
     pass
 
 
+def tree_source_hash():
+    """The hash `make` stamps into the library (ldsr_amd/csrc/Makefile SRCHASH), recomputed from the
+    tree next to this file; None when the sources are not there (an installed binary)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted(os.path.basename(f) for pat in ("*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(csrc, pat)))
+    files = [os.path.join(csrc, n) for n in names if n != "source_hash.h"]
+    files += [os.path.join(csrc, "Makefile"), os.path.join(_HERE, "..", "include", "ldsr_hip.h")]
+    if not names or not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -91,6 +112,13 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        # a prebuilt library that does not match the sources it sits next to must not pass for them
+        # (LDSR_HIP_SO: an explicitly chosen other build, e.g. the A/B runs of tools/ab.sh)
+        want = None if os.environ.get("LDSR_HIP_SO") else tree_source_hash()
+        got = L.ldsr_source_hash().decode()
+        if want is not None and got != want:
+            raise LdsrError("%s was built from other sources (library %s, tree %s): rebuild it with "
+                            "`make -C ldsr_amd/csrc`" % (SO_PATH, got, want))
         _LIB = L
     return _LIB
 

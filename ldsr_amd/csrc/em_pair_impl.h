@@ -70,6 +70,14 @@ __host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
            (pair_image_doubles(L, PP, QQ, LPC) + 8 * pair_strip_doubles(L) + pair_tri_doubles(PP, QQ, LPC)) * 8 <= 160 * 1024;
 }
 
+// Does the (L, LPC, PP, QQ) member leave room for a CU's waves: the series image and eight strips (wide
+// inputs -- padded p or q = 8, LEAD forms only: four) within 160 KiB.  ONE rule for the plan
+// (kernels_scan.hip pair_plan) and for what is compiled (em_pair_launch.inc).
+__host__ __device__ constexpr bool pair_member_fits(int L, int LPC, int PP, int QQ) {
+    const bool wide = PP > 4 || QQ > 4;
+    return (pair_image_doubles(L, PP, QQ, LPC) + (wide ? 4 : 8) * pair_strip_doubles(L)) * 8 <= 160 * 1024;
+}
+
 __device__ __forceinline__ double shfl_d(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
 // Cross-row step of the reverse scans.  After the four row-shift rounds lane l holds the

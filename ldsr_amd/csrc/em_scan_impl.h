@@ -481,9 +481,6 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp, int &wit) {
     constexpr int NL = 64 * W;
-    // (the cell index is the same in every lane of the wave group: say so, or its 64-bit form for the
-    // result addresses sits in a VGPR pair across the whole EM loop -- the config-3 kernel spilled it)
-    cell = __builtin_amdgcn_readfirstlane(cell);
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
     const int vl = wv * 64 + lane;            // virtual lane
@@ -1145,6 +1142,17 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         prm.status[cell] = (interrupted && it < prm.niter) ? 3 : (isfinite(lik) ? 0 : 1);
     }
     return interrupted;
+}
+
+// Does the (L, W, PP, QQ) member read its series image from global memory?  When the image does not fit a
+// CU's LDS (L >= 20 only: the short-chunk images always fit) and for every multi-wave cell.  ONE rule for
+// the plan (kernels_scan.hip) and for what is compiled (em_scan_launch.inc): a member exists in the form
+// the plan uses and in no other.
+__host__ __device__ constexpr bool scan_image_fits_lds(int L, int W, int PP, int QQ) {
+    return (scan_image_doubles(L, W, PP, QQ) + scan_xch_doubles(W)) * 8 <= 160 * 1024;
+}
+__host__ __device__ constexpr bool scan_uses_gimg(int L, int W, int PP, int QQ) {
+    return L >= 20 && (W > 1 || !scan_image_fits_lds(L, W, PP, QQ));
 }
 
 // Launch plan of a (T, PP, QQ) shape: chunk length, waves per cell, cells per workgroup, and

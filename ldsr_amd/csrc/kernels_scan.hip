@@ -3,6 +3,7 @@
 // (em_scan_L*.hip).
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "em_scan_impl.h"
 #include "em_pair_impl.h"
@@ -40,13 +41,12 @@ ScanPlan scan_plan(int T, int PP, int QQ) {
             if (T <= 64 * p.W * L) { p.L = L; break; }
     }
     if (!p.L) return p;
-    const size_t lds = (size_t)(scan_image_doubles(p.L, p.W, PP, QQ) + scan_xch_doubles(p.W)) * sizeof(double);
     // the image is read from global memory (raw buffer loads, L2 / L1 resident) when it does not
     // fit a CU's LDS (L >= 20 only: the short-chunk images always fit) and for every multi-wave
     // cell: one cell per workgroup would let an LDS image cap a CU at one or two cells, while the
     // global image leaves 4 (W = 2) or 2 (W = 4) cells per CU -- measured 1.5x faster at W = 2
-    p.gimg = p.L >= 20 && (p.W > 1 || lds > kLdsBytes);
-    if (!p.gimg && lds > kLdsBytes) return p;
+    p.gimg = scan_uses_gimg(p.L, p.W, PP, QQ);
+    if (!p.gimg && !scan_image_fits_lds(p.L, p.W, PP, QQ)) return p;
     p.cpb = p.W > 1 ? 1 : (p.gimg ? 4 : scan_wpb(p.L, PP, QQ));   // GIMG: two workgroups per CU by VGPRs
     p.ok = true;
     return p;
@@ -108,6 +108,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
     const bool wide = PP > 4 || QQ > 4;
     if ((lpc != 32 && lpc != 16) || PP > 8 || QQ > 8 || T <= 64) return p;
     if (wide && !(lead_form && ((lpc == 32 && T <= 512) || (lpc == 16 && T <= 256)))) return p;
+    if (lead_form && T > lpc * 16) return p;      // (LEAD forms: chunks of <= 16 steps)
     // every chunk length from 3 to 32: the shortest one wastes no lanes (four cells per wave: from 5)
     // (lanes 0 .. rp-1 own L steps, the others L-1: needs 1 <= rp <= nl)
     for (int L = (lpc == 16 ? 5 : 3); L <= 32; L++) {
@@ -116,9 +117,7 @@ PairPlan pair_plan(int T, int PP, int QQ, int lpc, bool lead_form) {
         if (rp >= 1 && rp <= nl) { p.L = L; break; }
     }
     if (!p.L) return p;
-    const size_t img = (size_t)pair_image_doubles(p.L, PP, QQ, lpc) * sizeof(double);
-    const size_t strip = (size_t)pair_strip_doubles(p.L) * sizeof(double);
-    if (img + (wide ? 4 : 8) * strip > kLdsBytes) return p;     // (wide: four waves per workgroup may have to do)
+    if (!pair_member_fits(p.L, lpc, PP, QQ)) return p;     // (wide: four waves per workgroup may have to do)
     p.wpb = 8;
     p.ok = true;
     return p;
@@ -175,4 +174,51 @@ hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_bl
         default: return hipErrorInvalidValue;
     }
 #undef CASE_L
+}
+
+
+// ---- what is compiled ------------------------------------------------------------------------------
+// Every instantiation of the scan and pair families this library holds, by the names rocprofv3 prints,
+// derived from the SAME predicates the launchers instantiate with (em_scan_launch.inc launch_one,
+// em_pair_launch.inc): tests/test_abi_and_host.py checks that this set equals what the launch plans can
+// return over the supported domain -- nothing unreachable is compiled, nothing reachable is missing.
+void em_kernel_inventory(std::string &out) {
+    static const int widths[] = {1, 2, 4, 8};
+    static const int Ls1[] = {2, 3, 4, 6, 8, 10, 12, 13, 14, 15, 16, 20, 24, 28, 32};
+    static const int LsW[] = {20, 24, 28, 32};
+    char buf[160];
+    auto scan_names = [&](int L, int W) {
+        for (int PP : widths)
+            for (int QQ : widths) {
+                const bool gimg = scan_uses_gimg(L, W, PP, QQ);
+                const bool lds = !gimg && W == 1 && scan_image_fits_lds(L, W, PP, QQ);
+                auto add = [&](bool q, bool g, bool f) {
+                    snprintf(buf, sizeof(buf), "em_scan_kernel<%d, %d, %d, %d, %s, %s, %s>\n", PP, QQ, L, W,
+                             q ? "true" : "false", g ? "true" : "false", f ? "true" : "false");
+                    out += buf;
+                };
+                if (gimg) { add(true, true, false); add(false, true, true); }
+                if (lds) { add(false, false, false); add(true, false, false); add(false, false, true); }
+            }
+    };
+    for (int L : Ls1) scan_names(L, 1);
+    for (int W : {2, 4})
+        for (int L : LsW) scan_names(L, W);
+    for (int lpc : {32, 16})
+        for (int L = (lpc == 16 ? 5 : 3); L <= 32; L++)
+            for (int PP : widths)
+                for (int QQ : widths) {
+                    if (!pair_member_fits(L, lpc, PP, QQ)) continue;
+                    const bool wide = PP > 4 || QQ > 4;
+                    auto add = [&](bool q, bool lead) {
+                        snprintf(buf, sizeof(buf), "em_pair_kernel<%d, %d, %d, %d, %s, %s>\n", PP, QQ, L, lpc,
+                                 q ? "true" : "false", lead ? "true" : "false");
+                        out += buf;
+                    };
+                    if (!wide) { add(false, false); add(true, false); }
+                    if (L <= 16) {                       // LEAD forms: chunks of <= 16 steps
+                        if (!wide) add(false, true);
+                        add(true, true);                 // (wide inputs: LEAD form, work-queue schedule only)
+                    }
+                }
 }

@@ -19,6 +19,7 @@
 #include "../../include/ldsr_hip.h"
 #include "ldsr_kernels.h"
 #include "em_pair_impl.h"      // (layout constants only)
+#include "source_hash.h"       // LDSR_SOURCE_HASH, written by the Makefile
 
 static thread_local std::string g_err;
 
@@ -35,7 +36,8 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *ldsr_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ldsr_version(void) { return "ldsr_hip 0.2.0 (gfx950)"; }
+extern "C" const char *ldsr_version(void) { return "ldsr_hip 0.4.0 (gfx950) src " LDSR_SOURCE_HASH; }
+extern "C" const char *ldsr_source_hash(void) { return LDSR_SOURCE_HASH; }
 
 extern "C" int ldsr_device_count(void) {
     int n = 0;
@@ -48,13 +50,22 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // ---- user interrupts ---------------------------------------------------------------------------
 // One host-pinned flag for the whole library: kernels launched while a callback is registered
 // poll it; only the thread that entered the library from outside (t_poll) runs the callback.
+// The registration is ONE immutable record published through one atomic pointer (callback and
+// argument as two atomics let a poller racing a re-registration call the old callback with the new
+// argument); replaced records live until ldsr_shutdown.  An entering call announces itself (`active`)
+// BEFORE it looks at the registration, and shutdown withdraws the registration BEFORE it looks at
+// `active`: with sequentially consistent atomics either the call sees no registration and never
+// touches the flag, or shutdown sees the call and leaves the flag alone.
+struct IntrReg {
+    int (*cb)(void *);
+    void *arg;
+};
 static struct {
     std::mutex mu;                    // serialises registration and shutdown
-    // (read without the mutex by every EM entry and by the polling thread: atomics)
-    std::atomic<int (*)(void *)> cb{nullptr};
-    std::atomic<void *> arg{nullptr};
+    std::atomic<const IntrReg *> reg{nullptr};
     std::atomic<int *> flag{nullptr};  // pinned, portable
     std::atomic<int> active{0};       // external EM calls in flight
+    std::vector<const IntrReg *> retired;
 } g_intr;
 static thread_local bool t_poll = false;     // this thread may run the callback
 static thread_local bool t_worker = false;   // a library worker thread: never runs it
@@ -67,23 +78,25 @@ extern "C" int ldsr_set_interrupt_callback(int (*callback)(void *), void *arg) {
         *(int *)p = 0;
         g_intr.flag.store((int *)p);
     }
-    g_intr.arg.store(arg);
-    g_intr.cb.store(callback);
+    const IntrReg *old = g_intr.reg.load();
+    if (old && callback && old->cb == callback && old->arg == arg) return LDSR_OK;     // (the shim registers before every call)
+    g_intr.reg.store(callback ? new IntrReg{callback, arg} : nullptr);
+    if (old) g_intr.retired.push_back(old);
     return LDSR_OK;
 }
 
-static const int *intr_flag_for_kernels() { return g_intr.cb.load() ? g_intr.flag.load() : nullptr; }
+static const int *intr_flag_for_kernels() { return g_intr.reg.load() ? g_intr.flag.load() : nullptr; }
 static bool intr_raised() {
     int *f = g_intr.flag.load();
-    return g_intr.cb.load() && f && *(volatile int *)f != 0;
+    return g_intr.reg.load() && f && *(volatile int *)f != 0;
 }
 
 // Run the callback (external caller thread only); raise the flag if it asks to stop.
 static void intr_poll() {
-    int (*cb)(void *) = g_intr.cb.load();
+    const IntrReg *r = g_intr.reg.load();
     int *f = g_intr.flag.load();
-    if (!t_poll || !cb || !f) return;
-    if (*(volatile int *)f == 0 && cb(g_intr.arg.load())) *(volatile int *)f = 1;
+    if (!t_poll || !r || !f) return;
+    if (*(volatile int *)f == 0 && r->cb(r->arg)) *(volatile int *)f = 1;
 }
 
 // RAII around an external EM entry: the outermost call on a non-worker thread becomes the poller
@@ -91,11 +104,16 @@ static void intr_poll() {
 struct IntrScope {
     bool owner = false;
     IntrScope() {
-        if (t_worker || t_poll || !g_intr.cb.load()) return;
+        if (t_worker || t_poll) return;
+        const int before = g_intr.active.fetch_add(1);       // announce first ...
+        if (!g_intr.reg.load()) {                             // ... then look (see above)
+            g_intr.active.fetch_sub(1);
+            return;
+        }
         owner = true;
         t_poll = true;
         int *f = g_intr.flag.load();
-        if (g_intr.active.fetch_add(1) == 0 && f) *(volatile int *)f = 0;
+        if (before == 0 && f) *(volatile int *)f = 0;
     }
     ~IntrScope() {
         if (!owner) return;
@@ -322,10 +340,15 @@ extern "C" void ldsr_shutdown(void) {
     }
     {
         std::lock_guard<std::mutex> lk(g_intr.mu);
-        if (g_intr.flag.load() && g_intr.active.load() == 0) {
-            g_intr.cb.store(nullptr);
-            (void)hipHostFree(g_intr.flag.load());
+        const IntrReg *cur = g_intr.reg.exchange(nullptr);     // withdraw first, then look at `active`
+        if (g_intr.active.load() == 0) {
+            if (g_intr.flag.load()) (void)hipHostFree(g_intr.flag.load());
             g_intr.flag.store(nullptr);
+            for (const IntrReg *r : g_intr.retired) delete r;
+            g_intr.retired.clear();
+            delete cur;
+        } else if (cur) {
+            g_intr.retired.push_back(cur);      // calls in flight: the flag and the records stay
         }
     }
     std::lock_guard<std::mutex> lk(g_arena_mu);
@@ -591,6 +614,26 @@ extern "C" int ldsr_em_plan_lead(int T, int p, int q, int niter, double tol, int
     const int lpc = lead_quad(T, tail, PP, QQ) ? 16 : 32;
     if (buf && len) em_pair_kernel_name(tail, PP, QQ, lpc, tol > 0.0 || PP > 4 || QQ > 4, buf, len, true);
     return lpc == 16 ? LDSR_ALGO_QUAD : LDSR_ALGO_PAIR;
+}
+
+// the kernel one Kalman_smoother pass of this shape runs (launch_smoother): the FIT form of the scan
+// kernel where its plan holds, else the serial smoother (returns LDSR_ALGO_SERIAL, empty name)
+extern "C" int ldsr_smooth_plan(int T, int p, int q, char *buf, size_t len) {
+    if (T < 2 || p < 1 || q < 1 || p > LDSR_MAXPQ || q > LDSR_MAXPQ) return -1;
+    const int PP = ldsr_pad_dim(p), QQ = ldsr_pad_dim(q);
+    if (buf && len) buf[0] = 0;
+    if (!em_scan_supported(T, PP, QQ)) return LDSR_ALGO_SERIAL;
+    if (buf && len) em_scan_kernel_name(T, PP, QQ, false, true, buf, len);
+    return LDSR_ALGO_SCAN;
+}
+
+// names of every compiled instantiation of the scan and pair families, one per line; returns the
+// length needed (including the terminating 0)
+extern "C" size_t ldsr_kernel_inventory(char *buf, size_t len) {
+    std::string s;
+    em_kernel_inventory(s);
+    if (buf && len) snprintf(buf, len, "%s", s.c_str());
+    return s.size() + 1;
 }
 
 extern "C" int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf,

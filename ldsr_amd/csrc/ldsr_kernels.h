@@ -94,6 +94,8 @@ void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, 
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);
+#include <string>
+void em_kernel_inventory(std::string &out);      // names of every compiled scan / pair instantiation, one per line
 hipError_t launch_gather_winners(const GatherParams &prm, hipStream_t stream);
 hipError_t launch_select_winners(const SelectParams &prm, hipStream_t stream);
 hipError_t launch_smooth(const SmoothParams &prm, int PP, int QQ, hipStream_t stream);

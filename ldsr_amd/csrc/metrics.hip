@@ -39,8 +39,15 @@ extern "C" double ldsr_metric_nse(int n, const double *yhat, const double *y) {
     return 1.0 - rss_of(n, yhat, y) / tss;
 }
 
+// (src/utils.cpp:37: sqrt(mean((y - yhat) * (y - yhat))) -- Rcpp sugar's mean over the squared
+// residuals, i.e. the two-pass long-double mean, not sum / n)
 extern "C" double ldsr_metric_nrmse(int n, const double *yhat, const double *y, double norm_const) {
-    return std::sqrt(rss_of(n, yhat, y) / n) / norm_const;
+    long double s = 0.0L;
+    for (int i = 0; i < n; i++) s += (y[i] - yhat[i]) * (y[i] - yhat[i]);
+    s /= n;
+    long double t = 0.0L;
+    for (int i = 0; i < n; i++) t += (y[i] - yhat[i]) * (y[i] - yhat[i]) - s;
+    return std::sqrt((double)(s + t / n)) / norm_const;
 }
 
 extern "C" double ldsr_metric_corr(int n, const double *x, const double *y) {

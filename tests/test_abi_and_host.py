@@ -127,7 +127,7 @@ def test_launch_plan_of_every_shape():
     # the pair family's limits: T, widths, and the eight-waves-per-CU rule for wide inputs
     for T, p, q, a3, a4 in ((64, 1, 2, -1, -1), (65, 1, 2, 3, 4), (512, 1, 2, 3, 4), (513, 1, 2, 3, -1),
                             (1024, 1, 2, 3, -1), (1025, 1, 2, -1, -1), (1000, 1, 4, -1, -1), (928, 1, 4, 3, -1),
-                            (800, 4, 4, 3, -1), (900, 4, 4, -1, -1), (512, 3, 3, 3, -1), (400, 3, 3, 3, 4),
+                            (800, 4, 4, 3, -1), (900, 4, 4, -1, -1), (512, 3, 3, 3, 4), (400, 3, 3, 3, 4),   # (512, 3, 3) x four: since round 4's unpadded image
                             (1000, 5, 1, -1, -1), (300, 1, 5, -1, -1)):
         assert plan(T, p, q, 0.0, 3)[0] == a3, (T, p, q)
         assert plan(T, p, q, 0.0, 4)[0] == a4, (T, p, q)
@@ -277,3 +277,64 @@ def test_cv_grid_host_logic_with_oracle_engine():
     np.testing.assert_allclose(r["Ycv"][1], best["fit"]["Y"][inst] + 2.5, rtol=1e-12)
     m = cv.calculate_metrics(r["Ycv"][1], y[inst] + 2.5, Z[1])
     assert np.isfinite(list(m.values())).all()
+
+
+def test_library_holds_exactly_the_kernels_a_plan_can_return():
+    """Round 3's library had grown to 44 MB: chunk length, lanes per cell, schedule, lead and image
+    form are template parameters, and members no launch plan could select were compiled too (LDS
+    forms of images that do not fit the LDS, global-image forms of images that do, two-cells-per-wave
+    members whose image and strips exceed 160 KiB).  Now the launchers instantiate with the SAME
+    constexpr predicates the plans use (scan_uses_gimg, pair_member_fits) and
+    ldsr_kernel_inventory() lists the result; this test enumerates the plans -- ldsr_em_plan for
+    every T of the supported domain, every padded width, both schedules, AUTO and the explicit
+    algorithms; ldsr_em_plan_lead over the tails of a closed-form lead; ldsr_smooth_plan for the FIT
+    forms -- and asserts reachable == compiled."""
+    import ctypes as C
+    from ldsr_amd import _lib
+    L = _lib.lib()
+    n = L.ldsr_kernel_inventory(None, 0)
+    buf = C.create_string_buffer(n)
+    L.ldsr_kernel_inventory(buf, n)
+    compiled = set(buf.value.decode().split())            # names contain ", ": re-join below
+    compiled = set(l for l in buf.value.decode().split("\n") if l)
+    assert len(compiled) > 1000 and all(k.startswith(("em_scan_kernel<", "em_pair_kernel<")) for k in compiled)
+
+    reach = set()
+    name = C.create_string_buffer(160)
+    widths = (1, 2, 4, 8)
+    for T in range(2, 8193):
+        for p in widths:
+            for q in widths:
+                if L.ldsr_smooth_plan(T, p, q, name, 160) == 2:
+                    reach.add(name.value.decode())
+                for tol in (0.0, 1e-5):
+                    for algo in (0, 2, 3, 4):
+                        if (algo in (3, 4) and (T > 1024 or p > 4 or q > 4)) or (algo == 4 and T > 512):
+                            continue                       # (outside the family: the plan says -1)
+                        a = L.ldsr_em_plan(T, p, q, 100, tol, algo, name, 160)
+                        if a in (2, 3, 4):
+                            reach.add(name.value.decode())
+    # closed-form leads: the tail is max(T - lead, 80) rounded up to a multiple of 16, at most 512 steps
+    for T in (600, 700, 813, 1000, 1024, 1200, 1536, 2000, 3000, 4000, 8000, 8192):
+        for tail in range(64, 529, 8):
+            lead = T - tail
+            if lead < 1:
+                continue
+            for p in widths:
+                for q in widths:
+                    for tol in (0.0, 1e-5):
+                        a = L.ldsr_em_plan_lead(T, p, q, 100, tol, 0, lead, name, 160)
+                        if a in (2, 3, 4):
+                            reach.add(name.value.decode())
+    # AUTO reports the member a device-filling launch gets; smaller launches of a lead fall back from
+    # four to two cells per wave (same tails, LPC = 32), which the explicit plans above do not cover:
+    # the LEAD forms at two cells per wave exist for every tail a four-cell form exists for
+    missing = sorted(reach - compiled)
+    assert not missing, missing[:10]
+    extra = sorted(compiled - reach)
+    lead32 = [k for k in extra if k.startswith("em_pair_kernel<") and k.endswith(", true>") and ", 32, " in k]
+    assert sorted(set(extra) - set(lead32)) == [], sorted(set(extra) - set(lead32))[:20]
+    # ... and those are reachable through smaller launches: the tail plan at lpc = 32 is the same rule
+    for k in lead32:
+        PP, QQ, Lc, lpc = [int(x) for x in k[len("em_pair_kernel<"):].split(", ")[:4]]
+        assert lpc == 32 and 3 <= Lc <= 16

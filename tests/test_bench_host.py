@@ -140,6 +140,7 @@ def test_host_entry_leg_builds_the_call_it_times(monkeypatch):
         import ctypes as C
         seen.update(S=S, T=T, p=p, q=q, shared=shared_uv, niter=niter, off=[off_[i] for i in range(S + 1)])
         n = off_[S]
+        assert isinstance(y, C.POINTER(C.c_double)) and isinstance(nit, C.POINTER(C.c_int))   # _lib.SIGNATURES' types
         src = np.full(n, niter, np.int32)
         C.memmove(nit, src.ctypes.data, 4 * n)
         return 0

@@ -12,7 +12,7 @@ objs=""
 for o in *.o; do
   b=${o%.o}
   if echo " $tus " | grep -q " $b "; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 --offload-compress -Wall -Wno-unused-function $flags -c $b.hip -o /tmp/ldsr_var_$name/$b.o &
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 --offload-compress --offload-compression-level=19 -Wall -Wno-unused-function $flags -c $b.hip -o /tmp/ldsr_var_$name/$b.o &
     objs="$objs /tmp/ldsr_var_$name/$b.o"
   else
     objs="$objs $o"
