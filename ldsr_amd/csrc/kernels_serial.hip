@@ -16,72 +16,85 @@
 // series_prep_kernel: one block per series.  Builds the zero-padded time-major copies of
 // u and v, and the theta-independent statistics (SeriesConst).
 // ---------------------------------------------------------------------------------------
-__device__ static bool invert_small(double *a, double *inv, int n) {
-    // Gauss-Jordan with partial pivoting on an n x n matrix stored with stride LDSR_MAXPQ;
-    // entries outside n x n are left untouched (identity padding).  One thread; `a` and the
-    // workspace `inv` live in LDS (a private array would sit in scratch memory and make every
-    // access a global-memory round trip).
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) inv[i * LDSR_MAXPQ + j] = (i == j) ? 1.0 : 0.0;
+// The small dense factorizations of series_prep, done by ONE WAVE (lane = column j, four row groups):
+// one thread doing them alone walks O(n^3) dependent LDS round trips -- 50 us of a 120 us series_prep at
+// q = 8, and the 16 x 16 padded products behind them another 25 us whatever q is (round 4).  Every
+// element sees the same operations in the same order as in the one-thread form, so the results are
+// unchanged.  `volatile`: the lanes exchange values through LDS in program order (one wave: lockstep,
+// in-order LDS), which per-thread alias analysis must not second-guess.
+typedef volatile double *vdp;
+
+// Gauss-Jordan with partial pivoting on an n x n matrix (stride LDSR_MAXPQ, n <= 16) in place; entries
+// outside n x n are left untouched (identity padding); `inv`: LDS workspace.  False if a pivot is 0.
+__device__ static bool invert_small(double *a_, double *inv_, int n, int lane) {
+    vdp a = a_, inv = inv_;
+    constexpr int M = LDSR_MAXPQ;
+    const int j = lane & 15, rg = lane >> 4;
+    const bool col = j < n;
+    for (int r = rg; r < n; r += 4)
+        if (col) inv[r * M + j] = (r == j) ? 1.0 : 0.0;
     for (int c = 0; c < n; c++) {
-        int piv = c;
-        double best = fabs(a[c * LDSR_MAXPQ + c]);
+        int piv = c;                                       // (every lane finds the same pivot)
+        double best = fabs(a[c * M + c]);
         for (int r = c + 1; r < n; r++) {
-            const double m = fabs(a[r * LDSR_MAXPQ + c]);
+            const double m = fabs(a[r * M + c]);
             if (m > best) { best = m; piv = r; }
         }
         if (!(best > 0.0) || !isfinite(best)) return false;
-        if (piv != c)
-            for (int j = 0; j < n; j++) {
-                double t = a[c * LDSR_MAXPQ + j];
-                a[c * LDSR_MAXPQ + j] = a[piv * LDSR_MAXPQ + j];
-                a[piv * LDSR_MAXPQ + j] = t;
-                t = inv[c * LDSR_MAXPQ + j];
-                inv[c * LDSR_MAXPQ + j] = inv[piv * LDSR_MAXPQ + j];
-                inv[piv * LDSR_MAXPQ + j] = t;
-            }
-        const double d = 1.0 / a[c * LDSR_MAXPQ + c];
-        for (int j = 0; j < n; j++) {
-            a[c * LDSR_MAXPQ + j] *= d;
-            inv[c * LDSR_MAXPQ + j] *= d;
+        if (piv != c && rg == 0 && col) {
+            double t = a[c * M + j];
+            a[c * M + j] = a[piv * M + j];
+            a[piv * M + j] = t;
+            t = inv[c * M + j];
+            inv[c * M + j] = inv[piv * M + j];
+            inv[piv * M + j] = t;
         }
-        for (int r = 0; r < n; r++) {
-            if (r == c) continue;
-            const double f = a[r * LDSR_MAXPQ + c];
-            for (int j = 0; j < n; j++) {
-                a[r * LDSR_MAXPQ + j] -= f * a[c * LDSR_MAXPQ + j];
-                inv[r * LDSR_MAXPQ + j] -= f * inv[c * LDSR_MAXPQ + j];
-            }
+        const double d = 1.0 / a[c * M + c];               // (read by every lane before lane c rescales it)
+        if (rg == 0 && col) {
+            a[c * M + j] = a[c * M + j] * d;
+            inv[c * M + j] = inv[c * M + j] * d;
+        }
+        for (int r = rg; r < n; r += 4) {
+            if (r == c || !col) continue;
+            const double f = a[r * M + c];                 // (read by the row's lanes before lane c clears it)
+            a[r * M + j] = a[r * M + j] - f * a[c * M + j];
+            inv[r * M + j] = inv[r * M + j] - f * inv[c * M + j];
         }
     }
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) a[i * LDSR_MAXPQ + j] = inv[i * LDSR_MAXPQ + j];
+    for (int r = rg; r < n; r += 4)
+        if (col) a[r * M + j] = inv[r * M + j];
     return true;
 }
 
 // Cholesky factor of the n x n SPD matrix `a` (stride LDSR_MAXPQ): on return `l` holds the lower
 // factor and `li` its inverse, both zero above the diagonal inside n x n and untouched
-// (identity padding) outside.  One thread.  False if a pivot is not positive.
-__device__ static bool chol_small(const double *a, double *l, double *li, int n) {
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) { l[i * LDSR_MAXPQ + j] = 0.0; li[i * LDSR_MAXPQ + j] = 0.0; }
+// (identity padding) outside.  One wave: lane i owns row i of l, then column i of li.  False if a
+// pivot is not positive.
+__device__ static bool chol_small(const double *a_, double *l_, double *li_, int n, int lane) {
+    const volatile double *a = a_;
+    vdp l = l_, li = li_;
+    constexpr int M = LDSR_MAXPQ;
+    const int i = lane;
+    if (i < n)
+        for (int j = 0; j < n; j++) { l[i * M + j] = 0.0; li[i * M + j] = 0.0; }
     for (int j = 0; j < n; j++) {
-        double d = a[j * LDSR_MAXPQ + j];
-        for (int k = 0; k < j; k++) d -= l[j * LDSR_MAXPQ + k] * l[j * LDSR_MAXPQ + k];
+        double d = a[j * M + j];                           // (every lane: the same value)
+        for (int k = 0; k < j; k++) d -= l[j * M + k] * l[j * M + k];
         if (!(d > 0.0) || !isfinite(d)) return false;
         const double ljj = sqrt(d);
-        l[j * LDSR_MAXPQ + j] = ljj;
-        for (int i = j + 1; i < n; i++) {
-            double e = a[i * LDSR_MAXPQ + j];
-            for (int k = 0; k < j; k++) e -= l[i * LDSR_MAXPQ + k] * l[j * LDSR_MAXPQ + k];
-            l[i * LDSR_MAXPQ + j] = e / ljj;
+        if (i == j) l[j * M + j] = ljj;
+        if (i > j && i < n) {
+            double e = a[i * M + j];
+            for (int k = 0; k < j; k++) e -= l[i * M + k] * l[j * M + k];
+            l[i * M + j] = e / ljj;
         }
     }
-    for (int c = 0; c < n; c++) {            // forward substitution, column c of the inverse
-        for (int i = c; i < n; i++) {
-            double e = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; k++) e -= l[i * LDSR_MAXPQ + k] * li[k * LDSR_MAXPQ + c];
-            li[i * LDSR_MAXPQ + c] = e / l[i * LDSR_MAXPQ + i];
+    if (i < n) {                                           // forward substitution, column c = i of the inverse
+        const int c = i;
+        for (int r = c; r < n; r++) {
+            double e = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; k++) e -= l[r * M + k] * li[k * M + c];
+            li[r * M + c] = e / l[r * M + r];
         }
     }
     return true;
@@ -299,28 +312,32 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
         bool ok = sc.n_obs > 0;
         // Cholesky factors of Svv / Tuu for the whitened images (before they are inverted in place)
-        if (v) ok = chol_small(sc.Svv_inv, sc.Lv, sc.Lv_inv, q) && ok;
-        if (u) ok = chol_small(sc.Tuu_inv, sc.Lu, sc.Lu_inv, p) && ok;
-        if (v) ok = invert_small(sc.Svv_inv, inv_ws, q) && ok;
-        if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p) && ok;
+        if (v) ok = chol_small(sc.Svv_inv, sc.Lv, sc.Lv_inv, q, lane) && ok;
+        if (u) ok = chol_small(sc.Tuu_inv, sc.Lu, sc.Lu_inv, p, lane) && ok;
+        if (v) ok = invert_small(sc.Svv_inv, inv_ws, q, lane) && ok;
+        if (u) ok = invert_small(sc.Tuu_inv, inv_ws, p, lane) && ok;
         // a caller-supplied lead (ldsr_em_batch_device_lead) that is not all-missing in this series
         // would silently drop observations: refuse the series like a singular one
         if (prm.img3 && prm.lead > 0 && sc.n_obs > 0 && sc.t_first_obs < prm.lead) ok = false;
-        sc.status = ok ? 0 : 2;
-        for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
-            double a = 0.0;
-            for (int ll = 0; ll <= kk; ll++) a += sc.Lv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];
-            sc.Syv_w[kk] = a;
+        if (lane == 0) {
+            sc.status = ok ? 0 : 2;
+            sc.rn_obs = 1.0 / (double)sc.n_obs;
+            sc.rTm1 = 1.0 / (double)(T - 1);
         }
-        sc.rn_obs = 1.0 / (double)sc.n_obs;
-        sc.rTm1 = 1.0 / (double)(T - 1);
-        for (int kk = 0; kk < LDSR_MAXPQ; kk++) {
+        // Lv^{-1} Syv and Svv^{-1} Syv: row kk by lane kk (left-to-right sums over the padded 16 columns,
+        // as the one-thread loops had them)
+        if (lane < LDSR_MAXPQ) {
+            const int kk = lane;
+            vdp Lvi = sc.Lv_inv, Sv = sc.Svv_inv, Syv = sc.Syv;
             double a = 0.0;
-            for (int ll = 0; ll < LDSR_MAXPQ; ll++) a += sc.Svv_inv[kk * LDSR_MAXPQ + ll] * sc.Syv[ll];
-            sc.wv[kk] = a;
+            for (int ll = 0; ll <= kk; ll++) a += Lvi[kk * LDSR_MAXPQ + ll] * Syv[ll];
+            sc.Syv_w[kk] = a;
+            double b = 0.0;
+            for (int ll = 0; ll < LDSR_MAXPQ; ll++) b += Sv[kk * LDSR_MAXPQ + ll] * Syv[ll];
+            sc.wv[kk] = b;
         }
     }
     __syncthreads();

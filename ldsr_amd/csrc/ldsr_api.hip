@@ -466,6 +466,7 @@ struct WsLayout {
     int max_blocks, img_L, img_NL, img2_L, img2_NL = 32, lead = 0;
     // cell order of the pair kernel's steady form (series_prep orders when order_on): set per launch
     bool order_on = false;
+    bool build_scan_img = true;        // false: a pair-family launch with no smoother pass behind it
     int order_cpb = 0, order_ntr = 0;
     const double *order_theta0 = nullptr;
     const int *order_off = nullptr;     // device copy of the cell offsets (behind the block table)
@@ -682,7 +683,7 @@ static int prepare_series(hipStream_t stream, int n_series, int T, int p, int q,
     pp.vp = (double *)(ws + L.vp);
     pp.sc = (SeriesConst *)(ws + L.sc);
     pp.queue = (int *)(ws + L.queue);
-    pp.img = L.img_stride ? (double *)(ws + L.img) : nullptr;
+    pp.img = (L.img_stride && L.build_scan_img) ? (double *)(ws + L.img) : nullptr;
     pp.img_stride = L.img_stride;
     pp.L = L.img_L;
     pp.NL = L.img_NL;
@@ -714,7 +715,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
                                 void *d_workspace, size_t workspace_bytes,
                                 const int *abort_flag = nullptr, int dense_hint = -1,
                                 int *algo_used = nullptr, int lead_hint = -1, int *lead_used = nullptr,
-                                int lead_force = 0, const int *plan_off = nullptr, int plan_ns = 0) {
+                                int lead_force = 0, const int *plan_off = nullptr, int plan_ns = 0,
+                                bool fit_follows = true) {
     int rc = check_common(n_series, T, p, q, d_y, cell_offsets);
     if (rc) return rc;
     rc = check_em(niter, tol);
@@ -820,6 +822,9 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const int cpb = cells_per_block(algo, cpw ? Te : T, PP, QQ, lpc, cpw ? lead : 0);
     WsLayout L = ws_layout(n_series, T, PP, QQ, shared_uv, n_cells, algo_layout,
                            cells_per_block(algo_layout, T, PP, QQ));
+    // (the scan kernel's image serves the winners' FIT pass of the restart-grid entries; the bare device
+    // entries run no smoother behind a pair-family launch: series_prep skips it -- 4096 values at config 2)
+    L.build_scan_img = fit_follows || !cpw;
     if (cpw) {       // the image of the member that runs (the room is for the largest)
         long sz = 0;
         em_pair_layout(Te, PP, QQ, lpc, &L.img2_L, &sz, lead > 0);
@@ -940,7 +945,8 @@ extern "C" int ldsr_em_batch_device_lead(int device, void *stream_, int n_series
     return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
                                 shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
                                 d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes, nullptr,
-                                lead_steps < 0 ? 1 : -1, nullptr, lead_steps < 0 ? 0 : lead_steps);
+                                lead_steps < 0 ? 1 : -1, nullptr, lead_steps < 0 ? 0 : lead_steps, nullptr, 0,
+                                nullptr, 0, false);
 }
 
 extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int T, int p, int q,
@@ -951,7 +957,8 @@ extern "C" int ldsr_em_batch_device(int device, void *stream_, int n_series, int
                                     double *d_liks, void *d_workspace, size_t workspace_bytes) {
     return em_batch_device_impl(device, (hipStream_t)stream_, n_series, T, p, q, d_y, d_u, d_v,
                                 shared_uv, cell_offsets, d_theta0, niter, tol, algo, d_theta, d_lik,
-                                d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes);
+                                d_n_iter, d_status, d_liks, 1, d_workspace, workspace_bytes, nullptr, -1,
+                                nullptr, -1, nullptr, 0, nullptr, 0, false);
 }
 
 // One Kalman_smoother pass (src/EM.cpp:22-131) for n cells on prepared series: the FIT form of
