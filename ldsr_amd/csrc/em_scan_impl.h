@@ -321,6 +321,21 @@ __host__ __device__ constexpr int scan_pairs(int PP, int QQ) { return (1 + PP + 
 __host__ __device__ constexpr long scan_image_doubles(int L, int W, int PP, int QQ) {
     return img_doubles(L, 64 * W, PP, QQ);
 }
+// STEADY form of the one-wave-per-cell kernel (em_scan_steady.h): fully observed series, chunks of 12..16
+// steps (T = 641..1024).  The first K0 = 64 / L chunks of a series are its transient block, done one step per
+// lane; their values are kept once more one step per lane (`tri`, [pair][lane][2]) behind the image.
+#ifndef LDSR_SCAN_STEADY
+#define LDSR_SCAN_STEADY 1
+#endif
+__host__ __device__ constexpr int scan_steady_k0(int L) { return 64 / L; }
+__host__ __device__ constexpr int scan_steady_ntr(int L) { return scan_steady_k0(L) * L - 1; }
+__host__ __device__ constexpr long scan_tri_doubles(int PP, int QQ) { return (long)64 * 2 * scan_pairs(PP, QQ); }
+__host__ __device__ constexpr long scan_steady_lds_doubles(int PP, int QQ) { return scan_tri_doubles(PP, QQ) + 16 + 8 * 32; }   // + env + carry records (em_scan_steady.h)
+__host__ __device__ constexpr bool scan_steady(int PP, int QQ, int L, int W) {
+    return LDSR_SCAN_STEADY && W == 1 && L >= 12 && L <= 16 &&
+           (scan_image_doubles(L, 1, PP, QQ) + scan_steady_lds_doubles(PP, QQ)) * 8 <= 160 * 1024;
+}
+
 // per-wave exchange records of a multi-wave cell (doubles): forward composite (8), reverse
 // composite (4), partial sums (XCH_SUMS), plus one slot for the queue pull
 #define XCH_SUMS 40
@@ -365,10 +380,34 @@ __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_S
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
+// State of one cell carried between the steady S loop and the generic G phase (em_scan_steady.h)
+template <int PP, int QQ>
+struct ScanCarry {
+    Theta<PP, QQ> th;          // whitened input coordinates, wave-uniform
+    double lik, lik1, lik2;
+    int it;
+    bool done;                 // the cell stopped: its results are stored
+    bool interrupted;
+    bool stay;                 // G phase: never return to the S loop (steady form switched off / shape without a block)
+};
+
+// GP: the G phase of the steady form -- start from *gp instead of theta0, and return (state in *gp,
+// gp->done = false) as soon as the cell's variance recursion settles within the transient block again
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG, bool GP = false>
 __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
-                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit);
+                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit,
+                                             ScanCarry<PP, QQ> *gp = nullptr);
+template <int L>
+__device__ __forceinline__ bool scan_steady_verdict(double V1, double A, double C, double Q, double R, int lane);
+template <int PP, int QQ, int L>
+__device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const double *ys, const double *tri, int s,
+                                                    int cell, int lane, int wave, int nl, int rp, int &wit, bool allowed);
+template <int PP, int QQ>
+__device__ __forceinline__ void scan_steady_write_env(const EmParams &prm, double *envp);
+
+// (the host can switch the steady form off per launch -- LDSR_SCAN_STEADY=0 in the environment: A/B runs)
+#define scan_steady_on() (prm.scan_steady != 0 && rp >= scan_steady_k0(L) && nl > scan_steady_k0(L))
 
 // A cell the work queue handed out after the host raised the interrupt flag: not computed, but
 // marked, so that an LDSR_EINTERRUPTED return never leaves stale numbers that look like results.
@@ -409,6 +448,17 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
         for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
         ys = smem;
         if constexpr (W > 1) xch = smem + IMG;
+        // steady form: the first NTR steps of the series once more, one step per lane, zero beyond
+        if constexpr (scan_steady(PP, QQ, L, W) && !FIT && !GIMG) {
+            constexpr int KPt = scan_pairs(PP, QQ), KVt = img_values(PP, QQ), NTRt = scan_steady_ntr(L);
+            double *tri_w = smem + IMG;
+            for (int i = threadIdx.x; i < KPt * 64 * 2; i += blockDim.x) {
+                const int c = i & 1, l = (i >> 1) & 63, m = (i >> 1) >> 6;      // step l = step l % L of lane l / L
+                const int vi = 2 * m + c;
+                tri_w[i] = (l < NTRt && vi < KVt) ? gimg[img_off(l % L, vi, KVt, 64, L) + (l / L) * 2] : 0.0;
+            }
+            if (threadIdx.x == 0) scan_steady_write_env<PP, QQ>(prm, tri_w + scan_tri_doubles(PP, QQ));
+        }
         __syncthreads();
     }
     // global image: buffer resource over the series image (out-of-range reads return 0)
@@ -437,6 +487,13 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
         }
     } else if constexpr (!QUEUE) {
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
+        if constexpr (scan_steady(PP, QQ, L, W) && !FIT && !GIMG) {
+            // (a kernel with the steady form has no second, inlined copy of the dense generic loop: switched off or
+            // without room for a transient block, the cell runs all its iterations in the G phase's function)
+            if (dense) em_scan_steady_cell<PP, QQ, L>(prm, ys, smem + IMG, s, c0 + wave, lane, wave, nl, rp, wit, scan_steady_on());
+            else em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
+            return;
+        }
         if (dense)
             em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
         else
@@ -453,6 +510,11 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
             if (aborted) { if (lane == 0) mark_cell_interrupted(prm, c0 + k); continue; }
+            if constexpr (scan_steady(PP, QQ, L, W) && !FIT && !GIMG) {
+                if (dense) aborted = em_scan_steady_cell<PP, QQ, L>(prm, ys, smem + IMG, s, c0 + k, lane, wave, nl, rp, wit, scan_steady_on());
+                else aborted = em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
+                continue;
+            }
             if (dense)
                 aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
             else
@@ -476,10 +538,12 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
 #define SCAN_TICK(k)
 #endif
 
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG, bool GP>
 __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
-                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit) {
+                                             int s, int cell, int lane, int wv, int nl, int rp, int &wit,
+                                             ScanCarry<PP, QQ> *gp) {
+    static_assert(!GP || (DENSE && W == 1 && !FIT && !GIMG), "G phase: fully observed series, one wave per cell, LDS image");
     constexpr int NL = 64 * W;
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
@@ -532,8 +596,9 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     }
 
     Theta<PP, QQ> th;
-    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-    if (sc->status != 0) {     // uniform over the cell's waves: no barrier is skipped unevenly
+    if constexpr (GP) th = gp->th;
+    else load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    if (!GP && sc->status != 0) {     // uniform over the cell's waves: no barrier is skipped unevenly
         if (lane == 0 && wv == 0) {
             if constexpr (!FIT) {
                 for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
@@ -559,9 +624,10 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         return false;
     }
 
-    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
+    if constexpr (!GP) white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
+    if constexpr (GP) { lik = gp->lik; lik1 = gp->lik1; lik2 = gp->lik2; it = gp->it; }
     bool interrupted = false;   // the host raised the interrupt flag (src/EM.cpp:261-262 polls too)
     // Per-step (J_t, g_t, h_t) kept in registers between the forward and the backward sweep.
     // Chunks longer than 16 steps (T > 1024) would need more than 256 VGPRs and drop to one
@@ -1124,7 +1190,16 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < PP; k++) th.B[k] = uniform_d(th.B[k]);
 #pragma unroll
         for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
+        if constexpr (GP) {
+            // back to the S loop as soon as this cell's variance recursion settles within the block again
+            if (!gp->stay && scan_steady_verdict<L>(th.V1, th.A, th.C, th.Q, th.R, lane)) {
+                gp->th = th; gp->lik = lik; gp->lik1 = lik1; gp->lik2 = lik2; gp->it = it;
+                gp->done = false; gp->interrupted = false;
+                return false;
+            }
+        }
     }
+    if constexpr (GP) { gp->done = true; gp->interrupted = interrupted; }
 
     if (lane == 0 && wv == 0) {
         if constexpr (!FIT) {
@@ -1154,6 +1229,8 @@ __host__ __device__ constexpr bool scan_image_fits_lds(int L, int W, int PP, int
 __host__ __device__ constexpr bool scan_uses_gimg(int L, int W, int PP, int QQ) {
     return L >= 20 && (W > 1 || !scan_image_fits_lds(L, W, PP, QQ));
 }
+
+#include "em_scan_steady.h"
 
 // Launch plan of a (T, PP, QQ) shape: chunk length, waves per cell, cells per workgroup, and
 // whether the series image is read from global memory (kernels_scan.hip).

@@ -1,0 +1,598 @@
+// em_scan_steady.h -- the STEADY form of the one-wave-per-cell kernel: fully observed series of 641..1024
+// steps (chunks of 12..16 steps), any padded p, q <= 8.  BASELINE config 3's path (T = 1000, p = 4, q = 8).
+//
+// The idea is em_pair_impl.h's (em_pair_body_steady), on 64 lanes per cell.  With every y_t observed the
+// variance side of the filter (Vp_t, K_t, Sigma_t, Vu_t, J_t, h_t: /root/reference/src/EM.cpp:76,86,88,100) is
+// the data-independent Riccati recursion, which reaches its fixed point geometrically.  The first
+// NTR = K0 L - 1 steps of the series (K0 = 64 / L chunks: 63 steps at L = 16) are done ONE STEP PER LANE -- a
+// 2x2 scan of the variance step matrices, an affine scan of the means, the reference's expressions from the
+// exact entry state; lane 63 is no transient step: its "entry state" is the state at t = NTR, and what it
+// evaluates there ARE the steady constants K, 1/Sigma, Vu, J, h, log Sigma.  Verdict (scan_steady_verdict):
+// one more step leaves Vp unchanged to 2^-48, every Sigma of the block positive, J^2 < 0.8.  A cell that
+// passes runs the steady sweeps on t >= NTR: only the mean recursions with constant multipliers -- 5 fp64
+// operations per step next to the p + q input products, where the generic sweeps take 43 -- no J / h
+// arrays, the smoothed variances of the steady region in closed form; then the block is swept backwards.
+//
+// A cell that fails (slow Riccati convergence: A near 1 with a tiny gain, mostly in the first EM
+// iterations) runs GENERIC iterations until it passes again: scan_g_phase, a real function (its own register
+// allocation, entered once per slow episode) around em_scan_cell<..., GP> -- the scan kernel's own E-step
+// and M-step, started from the carried state.  One cell per wave: nothing waits, nothing is shared, and
+// which form an iteration takes depends on the cell's theta only.
+#pragma once
+
+// ---- variance side of the transient block (explicit fma / mul only: the S loop and the G phase each
+// compile a copy and must decide alike).  Inclusive scan over the 64 lanes of the 2x2 step matrices
+// [[alpha, Q],[C2R, 1]] (one and the same for every step; scaled by an exact power of two so that
+// max(alpha, 1) c is in [0.5, 1); identity beyond step NTR-1), then Vp = (p00 V1 + p01) / (p10 V1 + p11) of
+// the lane before; then the reference's expressions, as in F2.
+struct ScanVarBlk { double Vp, sg, r0, K, Vu, AVu, J, Vp1; bool st; };
+template <int L>
+__device__ __forceinline__ ScanVarBlk scan_var_block(double V1, double A, double C, double Q, double R, int lane) {
+    constexpr int NTR = scan_steady_ntr(L);
+    ScanVarBlk b;
+    const double A2 = A * A, C2 = C * C;
+    const double C2R = C2 * fast_rcp(R), alpha = fma(Q, C2R, A2);
+    const bool trl = lane < NTR;
+    double Vp;
+    {
+        const double mxs = fmax(alpha, 1.0);
+        const int ke = -__builtin_amdgcn_frexp_exp(mxs);
+        const double cs = __builtin_amdgcn_ldexp(1.0, ke);
+        double p00 = trl ? alpha * cs : 1.0, p01 = trl ? Q * cs : 0.0;
+        double p10 = trl ? C2R * cs : 0.0, p11 = trl ? cs : 1.0;
+#define VSCAN_ROUND(Q00, Q01, Q10, Q11)                                                  \
+        {                                                                                \
+            const double q00 = Q00, q01 = Q01, q10 = Q10, q11 = Q11;                     \
+            const double r00 = fma(p00, q00, p01 * q10), r01 = fma(p00, q01, p01 * q11); \
+            const double r10 = fma(p10, q00, p11 * q10), r11 = fma(p10, q01, p11 * q11); \
+            p00 = r00; p01 = r01; p10 = r10; p11 = r11;                                  \
+        }
+#define VSCAN_RENORM                                                                              \
+        {   /* exact power-of-two rescale (projective coordinates are scale free) */             \
+            const double m = fmax(fmax(fabs(p00), fabs(p01)), fmax(fabs(p10), fabs(p11)));        \
+            const int e2 = 1 - __builtin_amdgcn_frexp_exp(m);                                     \
+            p00 = __builtin_amdgcn_ldexp(p00, e2); p01 = __builtin_amdgcn_ldexp(p01, e2);         \
+            p10 = __builtin_amdgcn_ldexp(p10, e2); p11 = __builtin_amdgcn_ldexp(p11, e2);         \
+        }
+#define VSCAN_SHR(n) VSCAN_ROUND(dpp1<DPP_ROW_SHR(n)>(p00), dppz<DPP_ROW_SHR(n)>(p01), dppz<DPP_ROW_SHR(n)>(p10), dpp1<DPP_ROW_SHR(n)>(p11))
+        VSCAN_SHR(1) VSCAN_SHR(2) VSCAN_SHR(4)
+        VSCAN_RENORM
+        VSCAN_SHR(8)
+        VSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, p00)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p01)),
+                    (dppd<DPP_ROW_BCAST15, 0xA>(0.0, p10)), (dppd<DPP_ROW_BCAST15, 0xA>(1.0, p11)))
+        VSCAN_RENORM
+        VSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, p00)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p01)),
+                    (dppd<DPP_ROW_BCAST31, 0xC>(0.0, p10)), (dppd<DPP_ROW_BCAST31, 0xC>(1.0, p11)))
+#undef VSCAN_SHR
+#undef VSCAN_RENORM
+#undef VSCAN_ROUND
+        double n_e = fma(p00, V1, p01), d_e = fma(p10, V1, p11);
+        n_e = dppd<DPP_WAVE_SHR1, 0xF>(V1, n_e);
+        d_e = dppd<DPP_WAVE_SHR1, 0xF>(1.0, d_e);
+        if (lane == 0) { n_e = V1; d_e = 1.0; }
+        Vp = n_e * fast_rcp(d_e);                            // entering step `lane` (lane >= NTR: t = NTR)
+    }
+    const double sg = fma(C2, Vp, R);
+    const double r0 = fast_rcp(sg);
+    const double w = Vp * r0;
+    b.K = C * w;                                             // src/EM.cpp:86
+    b.Vu = R * w;                                            // :88
+    b.Vp1 = fma(A2, b.Vu, Q);                                // :76
+    b.AVu = A * b.Vu;
+    b.J = b.AVu * fast_rcp(b.Vp1);                           // :100
+    b.Vp = Vp; b.sg = sg; b.r0 = r0;
+    // fixed point reached (lane 63), every Sigma of the block positive (a negative one is the generic
+    // iteration's business: lik = NaN); J^2 < 0.8 lets the closed-form variance sums drop J^(2 (T - NTR))
+    const double dV = b.Vp1 - Vp;
+    const bool conv = fabs(dV) <= 3.552713678800501e-15 * fabs(Vp) && Vp > 0.0 && b.J * b.J < 0.8;
+    const unsigned long long okm = __ballot(sg > 0.0 && sg < INFINITY);
+    const unsigned long long cvm = __ballot(conv);
+    b.st = okm == ~0ull && (cvm >> 63) != 0ull;
+    return b;
+}
+template <int L>
+__device__ __forceinline__ bool scan_steady_verdict(double V1, double A, double C, double Q, double R, int lane) {
+    return scan_var_block<L>(V1, A, C, Q, R, lane).st;
+}
+
+// State crosses the call THROUGH LDS: a by-value ScanCarry (22 doubles at p = 4, q = 8) and environment made
+// the allocator spill ~340 VGPRs around the call site and inside the S loop; with one int argument the S loop
+// keeps the allocation it has without any call (189 VGPRs, no scratch).  Behind the image and `tri`:
+// SCAN_ENV_DOUBLES of launch constants (written once per workgroup), then SCAN_CARRY_DOUBLES per wave.
+#define SCAN_ENV_DOUBLES 16
+#define SCAN_CARRY_DOUBLES 32
+struct ScanEnv {
+    int T, p, q, niter, liks_nanfill, pad;
+    double tol;
+    const SeriesConst *sc;      // prm.sc (indexed by s inside)
+    double *theta, *lik, *liks;
+    int *n_iter, *status;
+    const int *abort;
+};
+static_assert(sizeof(ScanEnv) <= SCAN_ENV_DOUBLES * 8, "ScanEnv must fit its LDS slot");
+__host__ __device__ constexpr long scan_steady_extra_doubles(int PP, int QQ) {
+    return scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + 8 * SCAN_CARRY_DOUBLES;
+}
+
+// ---- G phase: generic iterations of this wave's cell until its variance recursion settles within the
+// transient block again (or the cell stops: results stored, done).  `code` in: s, cell, wit packed by the
+// caller into the wave's LDS record; returns 0 = back to the S loop, 1 = done, 3 = done and interrupted.
+template <int PP, int QQ, int L>
+__device__ __attribute__((noinline)) int scan_g_phase(int wave) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr long IMG = scan_image_doubles(L, 1, PP, QQ);
+    const double *envp = smem + IMG + scan_tri_doubles(PP, QQ);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    double *rec = smem + IMG + scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + (long)wave * SCAN_CARRY_DOUBLES;
+    const ScanEnv *Ev = reinterpret_cast<const ScanEnv *>(envp);
+    auto ui = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto up = [&](auto *ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (decltype(ptr))(((unsigned long long)hi << 32) | lo);
+    };
+    EmParams prm;
+    prm.T = ui(Ev->T); prm.p = ui(Ev->p); prm.q = ui(Ev->q); prm.has_u = 1; prm.has_v = 1;
+    prm.niter = ui(Ev->niter); prm.liks_nanfill = ui(Ev->liks_nanfill); prm.tol = uniform_d(Ev->tol);
+    prm.sc = up(Ev->sc); prm.theta = up(Ev->theta); prm.lik = up(Ev->lik); prm.liks = up(Ev->liks);
+    prm.n_iter = up(Ev->n_iter); prm.status = up(Ev->status); prm.abort = up(Ev->abort);
+    prm.theta0 = nullptr; prm.yp = nullptr;
+    // the wave's record: [0] A, [1] C, [2] Q, [3] R, [4] mu1, [5] V1, [6..] B, D, then lik, lik1, lik2, it, s, cell, wit, stay
+    ScanCarry<PP, QQ> cs;
+    cs.th.A = uniform_d(rec[0]); cs.th.C = uniform_d(rec[1]); cs.th.Q = uniform_d(rec[2]);
+    cs.th.R = uniform_d(rec[3]); cs.th.mu1 = uniform_d(rec[4]); cs.th.V1 = uniform_d(rec[5]);
+#pragma unroll
+    for (int k = 0; k < PP; k++) cs.th.B[k] = uniform_d(rec[6 + k]);
+#pragma unroll
+    for (int k = 0; k < QQ; k++) cs.th.D[k] = uniform_d(rec[6 + PP + k]);
+    constexpr int O = 6 + PP + QQ;
+    static_assert(O + 8 <= SCAN_CARRY_DOUBLES, "carry record too small");
+    cs.lik = uniform_d(rec[O]); cs.lik1 = uniform_d(rec[O + 1]); cs.lik2 = uniform_d(rec[O + 2]);
+    cs.it = ui((int)rec[O + 3]);
+    const int s = ui((int)rec[O + 4]), cell = ui((int)rec[O + 5]);
+    int wit = ui((int)rec[O + 6]);
+    cs.stay = ui((int)rec[O + 7]) != 0;
+    cs.done = false; cs.interrupted = false;
+    const int lane = threadIdx.x & 63;
+    const int T = prm.T;
+    const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)smem, 0, 0, 0x00020000);   // (unused: LDS image)
+    em_scan_cell<PP, QQ, L, 1, true, false, false, true>(prm, smem, rs, nullptr, s, cell, lane, 0, nl, rp, wit, &cs);
+    if (lane == 0) {
+        rec[0] = cs.th.A; rec[1] = cs.th.C; rec[2] = cs.th.Q; rec[3] = cs.th.R; rec[4] = cs.th.mu1; rec[5] = cs.th.V1;
+#pragma unroll
+        for (int k = 0; k < PP; k++) rec[6 + k] = cs.th.B[k];
+#pragma unroll
+        for (int k = 0; k < QQ; k++) rec[6 + PP + k] = cs.th.D[k];
+        rec[O] = cs.lik; rec[O + 1] = cs.lik1; rec[O + 2] = cs.lik2; rec[O + 3] = (double)cs.it;
+        rec[O + 6] = (double)wit;
+    }
+    return (cs.done ? 1 : 0) | (cs.interrupted ? 2 : 0);
+}
+
+template <int PP, int QQ>
+__device__ __forceinline__ void scan_steady_write_env(const EmParams &prm, double *envp) {
+    static_assert(scan_steady_lds_doubles(PP, QQ) == scan_steady_extra_doubles(PP, QQ), "LDS layout of the steady form");
+    ScanEnv *E = reinterpret_cast<ScanEnv *>(envp);
+    E->T = prm.T; E->p = prm.p; E->q = prm.q; E->niter = prm.niter; E->liks_nanfill = prm.liks_nanfill; E->pad = 0;
+    E->tol = prm.tol; E->sc = prm.sc; E->theta = prm.theta; E->lik = prm.lik; E->liks = prm.liks;
+    E->n_iter = prm.n_iter; E->status = prm.status; E->abort = prm.abort;
+}
+
+// ---- one cell of this wave, start to finish: S loop (steady iterations) <-> G phase
+template <int PP, int QQ, int L>
+__device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const double *ys, const double *tri, int s,
+                                                    int cell, int lane, int wave, int nl, int rp, int &wit, bool allowed) {
+    constexpr int KP = scan_pairs(PP, QQ), KV = img_values(PP, QQ);
+    constexpr int K0 = scan_steady_k0(L), NTR = scan_steady_ntr(L);
+    constexpr int PF = KP <= 2 ? 4 : (KP <= 4 ? 2 : 1);      // steps the image is read ahead
+    constexpr int SBM = 0x6;                                 // what may still cross the barriers: VALU | SALU
+    constexpr bool BIGIMG = LDSR_SCAN_HI_BASE && (long)scan_image_doubles(L, 1, PP, QQ) * 8 > 65536;
+    cell = __builtin_amdgcn_readfirstlane(cell);
+    int hi_pairs = 4096;       // (second LDS base 64 KiB up for the far half of a large image: em_scan_cell)
+    if constexpr (BIGIMG) asm volatile("" : "+v"(hi_pairs));
+    const double *ys_hi = ys + 2 * hi_pairs;
+    auto val = [&](int j, int i) -> double {
+        const int e = img_off(j, i, KV, 64, L);
+        if (BIGIMG && e >= 8192) return ys_hi[e - 8192 + lane * 2];
+        return ys[e + lane * 2];
+    };
+    auto ldw = [&](int j, double (&w)[2 * KP]) {
+#pragma unroll
+        for (int i = 0; i < KV; i++) w[i] = val(j, i);
+    };
+    const int T = prm.T;
+    const int P = 6 + prm.p + prm.q;
+    const SeriesConst *__restrict__ sc = prm.sc + s;
+    const int n_obs = sc->n_obs;
+    const bool act = lane < nl;
+    const bool tail = lane < rp;
+    const int lastLane = nl - 1;
+    // (the caller checked rp >= K0 && nl > K0: the first K0 lanes own L steps, the block ends on a chunk boundary)
+
+    ScanCarry<PP, QQ> cs;
+    Theta<PP, QQ> &th = cs.th;
+    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    if (sc->status != 0) {
+        if (lane == 0) {
+            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+            prm.n_iter[cell] = 0;
+            if (prm.liks && prm.liks_nanfill)
+                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            prm.lik[cell] = NAN;
+            prm.status[cell] = 2;
+        }
+        return false;
+    }
+    white_in(th, (SeriesConstK)sc);
+    auto make_uniform = [&]() {
+        th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
+        th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);
+#pragma unroll
+        for (int k = 0; k < PP; k++) th.B[k] = uniform_d(th.B[k]);
+#pragma unroll
+        for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
+    };
+    make_uniform();
+    cs.lik = NAN; cs.lik1 = NAN; cs.lik2 = NAN;
+    cs.it = 0;
+    cs.done = false; cs.interrupted = false;
+    cs.stay = !allowed;        // (switched off, or no room for a transient block: every iteration in the G phase)
+    bool interrupted = false;
+
+    for (;;) {
+        // ================================================================= S loop: steady iterations
+        bool slow = false;
+        while (!cs.stay) {
+            const double A = th.A, C = th.C;
+            const ScanVarBlk vb = scan_var_block<L>(th.V1, A, C, th.Q, th.R, lane);
+            if (__builtin_expect(!vb.st, 0)) { slow = true; break; }
+            // ---- mean side of the transient block: Xp_{t+1} = A (1 - K_t C) Xp_t + (A K_t e_t + B u_t), affine
+            // with the gains just found: inclusive scan over the lanes, then the reference's expressions
+            const bool trl = lane < NTR;
+            auto tval = [&](int i) -> double { return tri[((i >> 1) * 64 + lane) * 2 + (i & 1)]; };
+            double e_t = tval(0), bu_t = 0.0;                       // (tri is zero for lane >= NTR)
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) e_t = fma(-th.D[q_], tval(1 + PP + q_), e_t);
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) bu_t = fma(th.B[p_], tval(1 + p_), bu_t);
+            const double K = vb.K, J = vb.J, Vu = vb.Vu, AVu = vb.AVu, r0 = vb.r0;
+            double Xp;
+            {
+                const double aKt = A * K;
+                double al = trl ? fma(-aKt, C, A) : 1.0, bl = trl ? fma(aKt, e_t, bu_t) : 0.0;
+#define MSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
+                MSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
+                MSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+                MSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
+#undef MSCAN_ROUND
+                Xp = fma(al, th.mu1, bl);
+                Xp = dppd<DPP_WAVE_SHR1, 0xF>(th.mu1, Xp);
+                if (lane == 0) Xp = th.mu1;
+            }
+            const double dl = fma(-C, Xp, e_t);
+            const double Xu = fma(K, dl, Xp);                       // :87
+            const double Xp1 = fma(A, Xu, bu_t);                    // :74
+            const double trJ = J;
+            const double trG = fma(-J, Xp1, Xu);
+            const double trH = fma(-J, AVu, Vu);
+            const double trLq = trl ? dl * r0 * dl : 0.0;           // :122
+            const double lg = log_pos(vb.sg);
+            const double trLg = trl ? lg : 0.0;
+            // the steady constants: lane 63's values (wave-uniform)
+            const double cK = readlane_d(K, 63), cJ = readlane_d(J, 63), cr = readlane_d(r0, 63), cVu = readlane_d(Vu, 63);
+            const double ch = readlane_d(trH, 63), clg = readlane_d(lg, 63), X_tr = readlane_d(Xp, 63);
+
+            // ============================================ steady sweeps over t = NTR .. T-1
+            // Lanes 0 .. K0-2 have no steady step, lane K0-1 keeps only its predicated step L-1 (= step NTR);
+            // lanes K0.. their whole chunks.
+            const bool body = act && lane >= K0;
+            const bool tail_s = tail && lane >= K0 - 1;
+            const double aK = A * cK, a = fma(-aK, C, A);           // Xp_{t+1} = a Xp_t + (A K e_t + B u_t)
+            double aL = 1.0, JL = 1.0;                              // a^(L-1), J^(L-1): multipliers of a whole chunk
+            {
+                double sa = a, sj = cJ;
+                bool have = false;
+#pragma unroll
+                for (int bit = 0; (1 << bit) <= L - 1; bit++) {
+                    if ((L - 1) & (1 << bit)) {
+                        if (!have) { aL = sa; JL = sj; have = true; }
+                        else { aL *= sa; JL *= sj; }
+                    }
+                    if ((2 << bit) <= L - 1) { sa *= sa; sj *= sj; }
+                }
+            }
+            // ---- F1: chunk composite of the affine mean recursion; e_t and B u_t stay in registers for F2
+            // (no J / h arrays here: 2 x 16 doubles)
+            double gv_[L], buv[L];
+            double al = 1.0, bl = 0.0;
+            auto f1s = [&](int j, const double (&w)[2 * KP]) {
+                double e = w[0], bu = 0.0;
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], w[1 + PP + q_], e);
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], w[1 + p_], bu);
+                gv_[j] = e;
+                buv[j] = bu;
+                bl = fma(a, bl, fma(aK, e, bu));
+            };
+            // (the image is read PF steps ahead through an explicit register ring pinned by scheduling barriers:
+            // left alone the scheduler either issues each read right before its use or hoists the reads of many
+            // steps at once -- 26 registers per step at (4,8) -- and spills the accumulators)
+            {
+                double W[PF][2 * KP];
+#pragma unroll
+                for (int d = 0; d < PF; d++) ldw(d, W[d]);
+                __builtin_amdgcn_sched_barrier(SBM);
+                if (body) {
+#pragma unroll
+                    for (int j = 0; j < L - 1; j++) {
+                        f1s(j, W[j % PF]);
+                        if (j + PF < L - 1) ldw(j + PF, W[j % PF]);
+                        __builtin_amdgcn_sched_barrier(SBM);
+                    }
+                    al = aL;
+                }
+                if (tail_s) {
+                    double Wt[2 * KP];
+                    ldw(L - 1, Wt);
+                    f1s(L - 1, Wt);
+                    al *= a;
+                }
+            }
+            // ---- inclusive scan over the 64 lanes, then the entry state of this lane
+#define SSCAN_ROUND(AB, BB) { const double ab = AB, bb = BB; bl = fma(al, bb, bl); al *= ab; }
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(1)>(al), dppz<DPP_ROW_SHR(1)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(2)>(al), dppz<DPP_ROW_SHR(2)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(4)>(al), dppz<DPP_ROW_SHR(4)>(bl))
+            SSCAN_ROUND(dpp1<DPP_ROW_SHR(8)>(al), dppz<DPP_ROW_SHR(8)>(bl))
+            SSCAN_ROUND((dppd<DPP_ROW_BCAST15, 0xA>(1.0, al)), (dppd<DPP_ROW_BCAST15, 0xA>(0.0, bl)))
+            SSCAN_ROUND((dppd<DPP_ROW_BCAST31, 0xC>(1.0, al)), (dppd<DPP_ROW_BCAST31, 0xC>(0.0, bl)))
+#undef SSCAN_ROUND
+            double Xq = fma(al, X_tr, bl);                           // after this lane's steps
+            Xq = dppd<DPP_WAVE_SHR1, 0xF>(X_tr, Xq);
+            if (lane == 0) Xq = X_tr;
+            // ---- F2: the reference's mean expressions with the steady gains
+            double lq = 0.0, Xuq = 0.0;
+            auto f2s = [&](int j) {
+                const double e = gv_[j];
+                const double dlq = fma(-C, Xq, e);
+                lq = fma(dlq, dlq, lq);                            // :122 (times 1/Sigma below)
+                Xuq = fma(cK, dlq, Xq);                            // :87
+                const double Xq1 = fma(A, Xuq, buv[j]);            // :74
+                double g = fma(-cJ, Xq1, Xuq);
+                if (j >= L - 2) {
+                    const bool fin = (lane == lastLane) && (j == (tail_s ? L - 1 : L - 2));
+                    g = fin ? Xuq : g;                             // step T-1: Xs = Xu
+                }
+                gv_[j] = g;
+                Xq = Xq1;
+            };
+            if (body) {
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) {
+                    f2s(j);
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(SBM);
+                }
+            }
+            if (tail_s) f2s(L - 1);
+            const double tLv = fma(Xuq, Xuq, cVu);
+            const int nst = (body ? L - 1 : 0) + (tail_s ? 1 : 0);    // steady steps of this lane
+            const double likq = fma(cr, lq, trLq);
+            const double lsp = fma((double)nst, clg, trLg);
+            // ---- reverse composite of the chunk (constant multiplier J), reverse scan
+            double Pi = 1.0, G = 0.0;
+            if (tail_s) { G = gv_[L - 1]; Pi = cJ; }
+            if (body) {
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) G = fma(cJ, G, gv_[j]);
+                Pi *= JL;
+            }
+#define RSCAN_ROUND(n) { const double Pb = dpp1<DPP_ROW_SHL(n)>(Pi), Gb = dppz<DPP_ROW_SHL(n)>(G); G = fma(Pi, Gb, G); Pi *= Pb; }
+            RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+            {   // later rows: lanes 16, 32, 48 hold the composites of rows 1..3
+                const double P3 = readlane_d(Pi, 48), G3 = readlane_d(G, 48);
+                const double P2 = readlane_d(Pi, 32), G2 = readlane_d(G, 32);
+                const double P1 = readlane_d(Pi, 16), G1 = readlane_d(G, 16);
+                const double G23 = fma(P2, G3, G2), P23 = P2 * P3;
+                const double G123 = fma(P1, G23, G1);
+                (void)P23;
+                const int row = lane >> 4;
+                const double Gs = row == 0 ? G123 : row == 1 ? G23 : row == 2 ? G3 : 0.0;
+                G = fma(Pi, Gs, G);
+            }
+            double Xn = dppd<DPP_WAVE_SHL1, 0xF>(0.0, G);
+            if (lane == 63) Xn = 0.0;
+            const double XsS = readlane_d(G, K0 - 1);               // Xs at t = NTR (step L-1 of lane K0-1)
+            // ---- B2: Xs_t = J Xs_{t+1} + g_t and the sums over Xs in ONE pass (no variance chain)
+            double aSyx = 0.0, aTx1x = 0.0, aPall = 0.0;
+            double aSxv[QQ], aTx1u[PP], aTux[PP];
+#pragma unroll
+            for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = 0.0;
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) { aTx1u[p_] = 0.0; aTux[p_] = 0.0; }
+            auto b2s = [&](int j, const double (&w)[2 * KP]) {
+                const double Xs = fma(cJ, Xn, gv_[j]);             // :101
+                aTx1x = fma(Xn, Xs, aTx1x);                        // :180 (Xn = 0 after step T-1)
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) {
+                    const double ut = w[1 + p_];                   // zero at t = T-1
+                    aTx1u[p_] = fma(Xn, ut, aTx1u[p_]);            // :190
+                    aTux[p_] = fma(ut, Xs, aTux[p_]);              // :191
+                }
+                aPall = fma(Xs, Xs, aPall);
+                aSyx = fma(w[0], Xs, aSyx);                        // :151
+#pragma unroll
+                for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(Xs, w[1 + PP + q_], aSxv[q_]);   // :159
+                Xn = Xs;
+            };
+            {
+                double V[PF][2 * KP];
+                if (tail_s) {
+                    double Vt[2 * KP];
+                    ldw(L - 1, Vt);
+                    b2s(L - 1, Vt);
+                }
+#pragma unroll
+                for (int d = 0; d < PF; d++) ldw(L - 2 - d, V[d]);
+                __builtin_amdgcn_sched_barrier(SBM);
+                if (body) {
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) {
+                        const int d = (L - 2 - j) % PF;
+                        b2s(j, V[d]);
+                        if (j - PF >= 0) ldw(j - PF, V[d]);
+                        __builtin_amdgcn_sched_barrier(SBM);
+                    }
+                }
+            }
+            // ---- smoothed variances of the steady region in closed form:  Vs_{T-1} = Vu,
+            // Vs_t = rho Vs_{t+1} + h with rho = J^2  =>  Vs_{T-1-k} = Vs* + (Vu - Vs*) rho^k
+            const int N = T - NTR;                                   // steps NTR .. T-1
+            const double rho = cJ * cJ;
+            const double romr = fast_rcp(1.0 - rho);
+            const double Vss = ch * romr;
+            const double dVs = cVu - Vss;
+            // (rho < 0.8 is part of the verdict and N >= 500: rho^(N-1) < 1e-48 is dropped)
+            const double VsS = Vss;                                  // Vs at t = NTR
+            const double sumVs = fma(dVs, romr, (double)N * Vss);    // sum_{t >= NTR} Vs_t
+            const double addPall = sumVs;                            // :181,:183
+            const double addTx1x = cJ * (sumVs - VsS);               // sum_{t=NTR}^{T-2} Vs_{t+1} J_t  (:180)
+            // ---- transient block backwards: composite of steps lane .. NTR-1 applied to (XsS, VsS)
+            double X0v, V0v;
+            {
+                int l2 = lane;         // (re-read the block's values through an index the compiler cannot match
+                asm volatile("" : "+v"(l2));   //  with the forward block's: they would stay live across the sweeps)
+                auto tval2 = [&](int i) -> double { return tri[((i >> 1) * 64 + l2) * 2 + (i & 1)]; };
+                double Pt = trl ? trJ : 1.0, Gt = trl ? trG : 0.0, Ht = trl ? trH : 0.0;
+#define RSCAN_ROUND(n)                                                     \
+                {                                                          \
+                    const double Pb = dpp1<DPP_ROW_SHL(n)>(Pt);            \
+                    const double Gb = dppz<DPP_ROW_SHL(n)>(Gt);            \
+                    const double Hb = dppz<DPP_ROW_SHL(n)>(Ht);            \
+                    Gt = fma(Pt, Gb, Gt);                                  \
+                    Ht = fma(Pt * Pt, Hb, Ht);                             \
+                    Pt *= Pb;                                              \
+                }
+                RSCAN_ROUND(1) RSCAN_ROUND(2) RSCAN_ROUND(4) RSCAN_ROUND(8)
+#undef RSCAN_ROUND
+                {   // full products across the rows (the terminal value at t = NTR is not zero)
+                    const double P3 = readlane_d(Pt, 48), G3 = readlane_d(Gt, 48), H3 = readlane_d(Ht, 48);
+                    const double P2 = readlane_d(Pt, 32), G2 = readlane_d(Gt, 32), H2 = readlane_d(Ht, 32);
+                    const double P1 = readlane_d(Pt, 16), G1 = readlane_d(Gt, 16), H1 = readlane_d(Ht, 16);
+                    const double G23 = fma(P2, G3, G2), H23 = fma(P2 * P2, H3, H2), P23 = P2 * P3;
+                    const double G123 = fma(P1, G23, G1), H123 = fma(P1 * P1, H23, H1), P123 = P1 * P23;
+                    const int row = lane >> 4;
+                    const double Gs = row == 0 ? G123 : row == 1 ? G23 : row == 2 ? G3 : 0.0;
+                    const double Hs = row == 0 ? H123 : row == 1 ? H23 : row == 2 ? H3 : 0.0;
+                    const double Ps = row == 0 ? P123 : row == 1 ? P23 : row == 2 ? P3 : 1.0;
+                    Gt = fma(Pt, Gs, Gt);
+                    Ht = fma(Pt * Pt, Hs, Ht);
+                    Pt *= Ps;
+                }
+                const double XsT = fma(Pt, XsS, Gt), VsT = fma(Pt * Pt, VsS, Ht);   // at step `lane` (lane >= NTR: at NTR)
+                double XsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, XsT);
+                double VsN = dppd<DPP_WAVE_SHL1, 0xF>(0.0, VsT);
+                if (lane == 63) { XsN = 0.0; VsN = 0.0; }
+                if (trl) {
+                    aTx1x = fma(XsN, XsT, fma(VsN, trJ, aTx1x));     // :180
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) {
+                        const double ut = tval2(1 + p_);
+                        aTx1u[p_] = fma(XsN, ut, aTx1u[p_]);
+                        aTux[p_] = fma(ut, XsT, aTux[p_]);
+                    }
+                    aPall += fma(XsT, XsT, VsT);
+                    aSyx = fma(tval2(0), XsT, aSyx);
+#pragma unroll
+                    for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(XsT, tval2(1 + PP + q_), aSxv[q_]);
+                }
+                X0v = XsT; V0v = VsT;                                // lane 0: Xs_0, Vs_0
+            }
+            // ---- one wave reduction, likelihood, stop rule, M-step (as em_scan_cell's)
+            Sums<PP, QQ> S;
+            {
+                constexpr int NB = 5;
+                constexpr int NR = NB + QQ + 2 * PP;
+                double red[NR];
+                red[0] = aSyx; red[1] = aTx1x; red[2] = aPall; red[3] = likq; red[4] = lsp;
+#pragma unroll
+                for (int k = 0; k < QQ; k++) red[NB + k] = aSxv[k];
+#pragma unroll
+                for (int k = 0; k < PP; k++) { red[NB + QQ + k] = aTx1u[k]; red[NB + QQ + PP + k] = aTux[k]; }
+                wave_sum_n<NR>(red);
+                red[1] += addTx1x; red[2] += addPall;
+                S.X0 = readlane_d(X0v, 0);                 // :218
+                S.V0 = readlane_d(V0v, 0);                 // :219
+                const double term0 = fma(S.X0, S.X0, S.V0);
+                const double termLast = readlane_d(tLv, lastLane);
+                S.Syx = red[0]; S.Tx1x = red[1];
+                S.Sxx = red[2];
+#pragma unroll
+                for (int k = 0; k < QQ; k++) S.Sxv[k] = red[NB + k];
+#pragma unroll
+                for (int k = 0; k < PP; k++) { S.Tx1u[k] = red[NB + QQ + k]; S.Tux[k] = red[NB + QQ + PP + k]; }
+                S.Txx = red[2] - termLast;                  // t = 0 .. T-2
+                S.Tx1x1 = red[2] - term0;                   // t = 1 .. T-1
+                cs.lik2 = cs.lik1;
+                cs.lik1 = cs.lik;
+                cs.lik = (-0.5 * n_obs * LDSR_LOG_2PI - 0.5 * (red[3] + red[4])) / n_obs;   // :113-124
+            }
+            int abort_now = 0;
+            if (prm.abort && ((++wit) & 63) == 0)
+                abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
+            interrupted = abort_now != 0;
+            if (prm.liks && lane == 0) prm.liks[(long)cell * prm.niter + cs.it] = cs.lik;
+            cs.it++;
+            bool stop = cs.it >= prm.niter || interrupted;
+            if (cs.it >= 3 && fabs(cs.lik - cs.lik1) < prm.tol && fabs(cs.lik1 - cs.lik2) < prm.tol) stop = true;  // :272
+            if (__builtin_amdgcn_readfirstlane((int)stop)) { cs.done = true; break; }   // theta stays the one that produced this fit
+            mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
+            make_uniform();
+        }
+        if (cs.done) {
+            // results of a cell that stopped in the S loop (em_scan_cell stores its own)
+            if (lane == 0) {
+                white_out(th, (SeriesConstK)sc);
+                store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+                if (prm.liks && prm.liks_nanfill)
+                    for (int i = cs.it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+                prm.n_iter[cell] = cs.it;
+                prm.lik[cell] = cs.lik;
+                prm.status[cell] = (interrupted && cs.it < prm.niter) ? 3 : (isfinite(cs.lik) ? 0 : 1);
+            }
+            return interrupted;
+        }
+        (void)slow;
+        // ================================================================= G phase: generic iterations
+        {
+            double *rec = const_cast<double *>(tri) + scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + (long)wave * SCAN_CARRY_DOUBLES;
+            constexpr int O = 6 + PP + QQ;
+            if (lane == 0) {
+                rec[0] = th.A; rec[1] = th.C; rec[2] = th.Q; rec[3] = th.R; rec[4] = th.mu1; rec[5] = th.V1;
+#pragma unroll
+                for (int k = 0; k < PP; k++) rec[6 + k] = th.B[k];
+#pragma unroll
+                for (int k = 0; k < QQ; k++) rec[6 + PP + k] = th.D[k];
+                rec[O] = cs.lik; rec[O + 1] = cs.lik1; rec[O + 2] = cs.lik2; rec[O + 3] = (double)cs.it;
+                rec[O + 4] = (double)s; rec[O + 5] = (double)cell; rec[O + 6] = (double)wit; rec[O + 7] = cs.stay ? 1.0 : 0.0;
+            }
+            const int code = __builtin_amdgcn_readfirstlane(scan_g_phase<PP, QQ, L>(wave));
+            if (code & 1) return (code & 2) != 0;
+            th.A = uniform_d(rec[0]); th.C = uniform_d(rec[1]); th.Q = uniform_d(rec[2]);
+            th.R = uniform_d(rec[3]); th.mu1 = uniform_d(rec[4]); th.V1 = uniform_d(rec[5]);
+#pragma unroll
+            for (int k = 0; k < PP; k++) th.B[k] = uniform_d(rec[6 + k]);
+#pragma unroll
+            for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(rec[6 + PP + k]);
+            cs.lik = uniform_d(rec[O]); cs.lik1 = uniform_d(rec[O + 1]); cs.lik2 = uniform_d(rec[O + 2]);
+            cs.it = __builtin_amdgcn_readfirstlane((int)rec[O + 3]);
+            wit = __builtin_amdgcn_readfirstlane((int)rec[O + 6]);
+        }
+    }
+}

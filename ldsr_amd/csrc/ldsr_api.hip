@@ -430,6 +430,12 @@ static bool order_enabled() {
     return on;
 }
 
+// LDSR_SCAN_STEADY=0: fully observed series take the generic sweeps in the one-wave-per-cell kernel (A/B runs)
+static bool scan_steady_enabled() {
+    static const bool on = [] { const char *e = getenv("LDSR_SCAN_STEADY"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool pair_enabled() {
     static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
     return on;
@@ -914,6 +920,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.n_iter = d_n_iter; prm.status = d_status;
     prm.queue = (int *)(ws + L.queue);
     prm.perm = steady_launch ? (const int *)(ws + L.perm) : nullptr;
+    prm.scan_steady = scan_steady_enabled() ? 1 : 0;
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
     int slot;

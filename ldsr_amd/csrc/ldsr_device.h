@@ -309,6 +309,7 @@ struct EmParams {
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
     const int *perm;         // pair kernel, steady form: position -> cell (slowest cells first), or null
+    int scan_steady;         // scan kernel: fully observed series may take the steady form (em_scan_steady.h)
     const double *theta0;    // [n_cells][6+p+q]
     double *theta, *lik, *liks;
     int *n_iter, *status;

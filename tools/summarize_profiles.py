@@ -131,6 +131,16 @@ def main():
                                                           e["bench_kernel_ms_unprofiled"], e["valu_insts_per_unit"],
                                                           e["lds_insts_per_unit"], e["hbm_bytes_per_launch_raw"] / 1e3,
                                                           e["hbm_bytes_per_launch"] / 1e3))
+    # the other mask and the converged runs (tools/collect_profiles.sh "extra"): one unprofiled bench line each
+    for f in sorted(glob.glob(os.path.join(src, "extra", "*_bench.json"))):
+        try:
+            line = json.loads(open(f).read().strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            print("skipped", f)
+            continue
+        json.dump(line, open(os.path.join(prof, "%s_%s" % (rnd, os.path.basename(f))), "w"))
+        print(os.path.basename(f), "%.4g units/s, %.3f ms/step, kernel %.3f ms %s"
+              % (line["value"], line["ms_per_step"], line["roofline"]["kernel_ms"], line["roofline"]["kernel"]))
     summ = {"_about": "rocprofv3 --pmc passes of `python3 bench.py --workload W --steps 3 --warmup 1 "
                       "--no-cpu-baseline` on MI355X, summarised by tools/summarize_profiles.py; per-launch "
                       "averages of the EM kernel.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
