@@ -14,10 +14,14 @@
 // arrays, the smoothed variances of the steady region in closed form; then the block is swept backwards.
 //
 // A cell that fails (slow Riccati convergence: A near 1 with a tiny gain, mostly in the first EM
-// iterations) runs GENERIC iterations until it passes again: scan_g_phase, a real function (its own register
-// allocation, entered once per slow episode) around em_scan_cell<..., GP> -- the scan kernel's own E-step
-// and M-step, started from the carried state.  One cell per wave: nothing waits, nothing is shared, and
-// which form an iteration takes depends on the cell's theta only.
+// iterations) needs GENERIC iterations.  Both loops inlined in one kernel make the register allocator spill
+// in the colder one, and a call from the steady loop to a generic function costs the steady loop ~130 scratch
+// accesses per iteration (EXPERIMENTS.md R4.7), so the two forms are two KERNELS and a run is three launches
+// on one stream (EmParams.phase): (1) em_scan_kernel runs generic iterations on every cell until its verdict
+// passes -- at theta0 for ~96 % of config 3's cells, within ten iterations for the rest -- and leaves the state
+// in the cell's carry record; (2) em_scan_steady_kernel runs the steady iterations to the end, or gives a cell
+// whose verdict fails again back (state SLOW, the series' n_slow counted up); (3) em_scan_kernel finishes
+// those, if any.  Which form an iteration takes depends on the cell's theta only.
 #pragma once
 
 // ---- variance side of the transient block (explicit fma / mul only: the S loop and the G phase each
@@ -95,95 +99,10 @@ __device__ __forceinline__ bool scan_steady_verdict(double V1, double A, double 
     return scan_var_block<L>(V1, A, C, Q, R, lane).st;
 }
 
-// State crosses the call THROUGH LDS: a by-value ScanCarry (22 doubles at p = 4, q = 8) and environment made
-// the allocator spill ~340 VGPRs around the call site and inside the S loop; with one int argument the S loop
-// keeps the allocation it has without any call (189 VGPRs, no scratch).  Behind the image and `tri`:
-// SCAN_ENV_DOUBLES of launch constants (written once per workgroup), then SCAN_CARRY_DOUBLES per wave.
-#define SCAN_ENV_DOUBLES 16
-#define SCAN_CARRY_DOUBLES 32
-struct ScanEnv {
-    int T, p, q, niter, liks_nanfill, pad;
-    double tol;
-    const SeriesConst *sc;      // prm.sc (indexed by s inside)
-    double *theta, *lik, *liks;
-    int *n_iter, *status;
-    const int *abort;
-};
-static_assert(sizeof(ScanEnv) <= SCAN_ENV_DOUBLES * 8, "ScanEnv must fit its LDS slot");
-__host__ __device__ constexpr long scan_steady_extra_doubles(int PP, int QQ) {
-    return scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + 8 * SCAN_CARRY_DOUBLES;
-}
-
-// ---- G phase: generic iterations of this wave's cell until its variance recursion settles within the
-// transient block again (or the cell stops: results stored, done).  `code` in: s, cell, wit packed by the
-// caller into the wave's LDS record; returns 0 = back to the S loop, 1 = done, 3 = done and interrupted.
-template <int PP, int QQ, int L>
-__device__ __attribute__((noinline)) int scan_g_phase(int wave) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr long IMG = scan_image_doubles(L, 1, PP, QQ);
-    const double *envp = smem + IMG + scan_tri_doubles(PP, QQ);
-    wave = __builtin_amdgcn_readfirstlane(wave);
-    double *rec = smem + IMG + scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + (long)wave * SCAN_CARRY_DOUBLES;
-    const ScanEnv *Ev = reinterpret_cast<const ScanEnv *>(envp);
-    auto ui = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
-    auto up = [&](auto *ptr) {
-        const unsigned long long v = (unsigned long long)ptr;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-        return (decltype(ptr))(((unsigned long long)hi << 32) | lo);
-    };
-    EmParams prm;
-    prm.T = ui(Ev->T); prm.p = ui(Ev->p); prm.q = ui(Ev->q); prm.has_u = 1; prm.has_v = 1;
-    prm.niter = ui(Ev->niter); prm.liks_nanfill = ui(Ev->liks_nanfill); prm.tol = uniform_d(Ev->tol);
-    prm.sc = up(Ev->sc); prm.theta = up(Ev->theta); prm.lik = up(Ev->lik); prm.liks = up(Ev->liks);
-    prm.n_iter = up(Ev->n_iter); prm.status = up(Ev->status); prm.abort = up(Ev->abort);
-    prm.theta0 = nullptr; prm.yp = nullptr;
-    // the wave's record: [0] A, [1] C, [2] Q, [3] R, [4] mu1, [5] V1, [6..] B, D, then lik, lik1, lik2, it, s, cell, wit, stay
-    ScanCarry<PP, QQ> cs;
-    cs.th.A = uniform_d(rec[0]); cs.th.C = uniform_d(rec[1]); cs.th.Q = uniform_d(rec[2]);
-    cs.th.R = uniform_d(rec[3]); cs.th.mu1 = uniform_d(rec[4]); cs.th.V1 = uniform_d(rec[5]);
-#pragma unroll
-    for (int k = 0; k < PP; k++) cs.th.B[k] = uniform_d(rec[6 + k]);
-#pragma unroll
-    for (int k = 0; k < QQ; k++) cs.th.D[k] = uniform_d(rec[6 + PP + k]);
-    constexpr int O = 6 + PP + QQ;
-    static_assert(O + 8 <= SCAN_CARRY_DOUBLES, "carry record too small");
-    cs.lik = uniform_d(rec[O]); cs.lik1 = uniform_d(rec[O + 1]); cs.lik2 = uniform_d(rec[O + 2]);
-    cs.it = ui((int)rec[O + 3]);
-    const int s = ui((int)rec[O + 4]), cell = ui((int)rec[O + 5]);
-    int wit = ui((int)rec[O + 6]);
-    cs.stay = ui((int)rec[O + 7]) != 0;
-    cs.done = false; cs.interrupted = false;
-    const int lane = threadIdx.x & 63;
-    const int T = prm.T;
-    const int nl = (T + L - 1) / L, rp = T - nl * (L - 1);
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)smem, 0, 0, 0x00020000);   // (unused: LDS image)
-    em_scan_cell<PP, QQ, L, 1, true, false, false, true>(prm, smem, rs, nullptr, s, cell, lane, 0, nl, rp, wit, &cs);
-    if (lane == 0) {
-        rec[0] = cs.th.A; rec[1] = cs.th.C; rec[2] = cs.th.Q; rec[3] = cs.th.R; rec[4] = cs.th.mu1; rec[5] = cs.th.V1;
-#pragma unroll
-        for (int k = 0; k < PP; k++) rec[6 + k] = cs.th.B[k];
-#pragma unroll
-        for (int k = 0; k < QQ; k++) rec[6 + PP + k] = cs.th.D[k];
-        rec[O] = cs.lik; rec[O + 1] = cs.lik1; rec[O + 2] = cs.lik2; rec[O + 3] = (double)cs.it;
-        rec[O + 6] = (double)wit;
-    }
-    return (cs.done ? 1 : 0) | (cs.interrupted ? 2 : 0);
-}
-
-template <int PP, int QQ>
-__device__ __forceinline__ void scan_steady_write_env(const EmParams &prm, double *envp) {
-    static_assert(scan_steady_lds_doubles(PP, QQ) == scan_steady_extra_doubles(PP, QQ), "LDS layout of the steady form");
-    ScanEnv *E = reinterpret_cast<ScanEnv *>(envp);
-    E->T = prm.T; E->p = prm.p; E->q = prm.q; E->niter = prm.niter; E->liks_nanfill = prm.liks_nanfill; E->pad = 0;
-    E->tol = prm.tol; E->sc = prm.sc; E->theta = prm.theta; E->lik = prm.lik; E->liks = prm.liks;
-    E->n_iter = prm.n_iter; E->status = prm.status; E->abort = prm.abort;
-}
-
-// ---- one cell of this wave, start to finish: S loop (steady iterations) <-> G phase
+// ---- one cell of this wave: steady iterations from its carry record to the end (or until the verdict fails)
 template <int PP, int QQ, int L>
 __device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const double *ys, const double *tri, int s,
-                                                    int cell, int lane, int wave, int nl, int rp, int &wit, bool allowed) {
+                                                    int cell, int lane, int nl, int rp, int &wit) {
     constexpr int KP = scan_pairs(PP, QQ), KV = img_values(PP, QQ);
     constexpr int K0 = scan_steady_k0(L), NTR = scan_steady_ntr(L);
     constexpr int PF = KP <= 2 ? 4 : (KP <= 4 ? 2 : 1);      // steps the image is read ahead
@@ -211,21 +130,11 @@ __device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const d
     const int lastLane = nl - 1;
     // (the caller checked rp >= K0 && nl > K0: the first K0 lanes own L steps, the block ends on a chunk boundary)
 
-    ScanCarry<PP, QQ> cs;
-    Theta<PP, QQ> &th = cs.th;
-    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-    if (sc->status != 0) {
-        if (lane == 0) {
-            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
-            prm.n_iter[cell] = 0;
-            if (prm.liks && prm.liks_nanfill)
-                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
-            prm.lik[cell] = NAN;
-            prm.status[cell] = 2;
-        }
-        return false;
-    }
-    white_in(th, (SeriesConstK)sc);
+    struct { double lik, lik1, lik2; int it; } cs;
+    Theta<PP, QQ> th;
+    double *rec = prm.carry + (long)cell * SCAN_CARRY_DOUBLES;
+    if (scan_carry_state<PP, QQ>(rec) != SCAN_CELL_READY) return false;     // done in the first launch
+    scan_carry_load<PP, QQ>(rec, th, cs.lik, cs.lik1, cs.lik2, cs.it);
     auto make_uniform = [&]() {
         th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
         th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);
@@ -234,20 +143,20 @@ __device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const d
 #pragma unroll
         for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
     };
-    make_uniform();
-    cs.lik = NAN; cs.lik1 = NAN; cs.lik2 = NAN;
-    cs.it = 0;
-    cs.done = false; cs.interrupted = false;
-    cs.stay = !allowed;        // (switched off, or no room for a transient block: every iteration in the G phase)
     bool interrupted = false;
 
-    for (;;) {
-        // ================================================================= S loop: steady iterations
-        bool slow = false;
-        while (!cs.stay) {
+    {
+        for (;;) {
             const double A = th.A, C = th.C;
             const ScanVarBlk vb = scan_var_block<L>(th.V1, A, C, th.Q, th.R, lane);
-            if (__builtin_expect(!vb.st, 0)) { slow = true; break; }
+            if (__builtin_expect(!vb.st || cs.it == prm.giveback_it, 0)) {
+                // given back: generic iterations to the end in the third launch
+                if (lane == 0) {
+                    scan_carry_store<PP, QQ>(rec, th, cs.lik, cs.lik1, cs.lik2, cs.it, SCAN_CELL_SLOW);
+                    atomicAdd(prm.n_slow + s, 1);
+                }
+                return false;
+            }
             // ---- mean side of the transient block: Xp_{t+1} = A (1 - K_t C) Xp_t + (A K_t e_t + B u_t), affine
             // with the gains just found: inclusive scan over the lanes, then the reference's expressions
             const bool trl = lane < NTR;
@@ -551,48 +460,70 @@ __device__ __forceinline__ bool em_scan_steady_cell(const EmParams &prm, const d
             cs.it++;
             bool stop = cs.it >= prm.niter || interrupted;
             if (cs.it >= 3 && fabs(cs.lik - cs.lik1) < prm.tol && fabs(cs.lik1 - cs.lik2) < prm.tol) stop = true;  // :272
-            if (__builtin_amdgcn_readfirstlane((int)stop)) { cs.done = true; break; }   // theta stays the one that produced this fit
+            if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
             mstep_update_white<PP, QQ>(th, S, (SeriesConstK)sc, T);
             make_uniform();
         }
-        if (cs.done) {
-            // results of a cell that stopped in the S loop (em_scan_cell stores its own)
-            if (lane == 0) {
-                white_out(th, (SeriesConstK)sc);
-                store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
-                if (prm.liks && prm.liks_nanfill)
-                    for (int i = cs.it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
-                prm.n_iter[cell] = cs.it;
-                prm.lik[cell] = cs.lik;
-                prm.status[cell] = (interrupted && cs.it < prm.niter) ? 3 : (isfinite(cs.lik) ? 0 : 1);
+    }
+    if (lane == 0) {
+        white_out(th, (SeriesConstK)sc);
+        store_theta(th, prm.theta + (long)cell * P, prm.p, prm.q);
+        if (prm.liks && prm.liks_nanfill)
+            for (int i = cs.it; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+        prm.n_iter[cell] = cs.it;
+        prm.lik[cell] = cs.lik;
+        prm.status[cell] = (interrupted && cs.it < prm.niter) ? 3 : (isfinite(cs.lik) ? 0 : 1);
+        rec[6 + PP + QQ + 4] = (double)SCAN_CELL_DONE;
+    }
+    return interrupted;
+}
+
+// ---- the second launch of a steady run: one wave per cell, the series image and `tri` in LDS.  Same block
+// table and schedule as em_scan_kernel's launches around it (its own queue heads).
+template <int PP, int QQ, int L, bool QUEUE>
+__global__ __launch_bounds__(512) void em_scan_steady_kernel(EmParams prm) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr long IMG = scan_image_doubles(L, 1, PP, QQ);
+    constexpr int KP = scan_pairs(PP, QQ), KV = img_values(PP, QQ), NTR = scan_steady_ntr(L);
+    const int b = blockIdx.x;
+    const int s = prm.blk_series[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];   // QUEUE: the series' cells; else the block's
+    const int T = prm.T;
+    if (prm.sc[s].n_obs != T) return;        // a series with missing observations: done by the first launch
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nl = (T + L - 1) / L;
+    const int rp = T - nl * (L - 1);
+    const double *gimg = prm.img + (long)s * prm.img_stride;
+    for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+    // the first NTR steps of the series once more, one step per lane, zero beyond
+    double *tri = smem + IMG;
+    for (int i = threadIdx.x; i < KP * 64 * 2; i += blockDim.x) {
+        const int c = i & 1, l = (i >> 1) & 63, m = (i >> 1) >> 6;      // step l = step l % L of lane l / L
+        const int vi = 2 * m + c;
+        tri[i] = (l < NTR && vi < KV) ? gimg[img_off(l % L, vi, KV, 64, L) + (l / L) * 2] : 0.0;
+    }
+    __syncthreads();
+    int wit = 63;                            // (the first iteration polls the host's interrupt flag: an earlier launch may have seen it)
+    if constexpr (!QUEUE) {
+        if (wave >= nc) return;
+        em_scan_steady_cell<PP, QQ, L>(prm, smem, tri, s, c0 + wave, lane, nl, rp, wit);
+    } else {
+        bool aborted = false;
+        for (int pulls = 0; pulls <= nc; pulls++) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(prm.queue + s, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= nc) break;
+            if (aborted) {
+                double *rec = prm.carry + (long)(c0 + k) * SCAN_CARRY_DOUBLES;
+                if (scan_carry_state<PP, QQ>(rec) == SCAN_CELL_READY && lane == 0) {
+                    mark_cell_interrupted(prm, c0 + k);
+                    rec[6 + PP + QQ + 4] = (double)SCAN_CELL_DONE;
+                }
+                continue;
             }
-            return interrupted;
-        }
-        (void)slow;
-        // ================================================================= G phase: generic iterations
-        {
-            double *rec = const_cast<double *>(tri) + scan_tri_doubles(PP, QQ) + SCAN_ENV_DOUBLES + (long)wave * SCAN_CARRY_DOUBLES;
-            constexpr int O = 6 + PP + QQ;
-            if (lane == 0) {
-                rec[0] = th.A; rec[1] = th.C; rec[2] = th.Q; rec[3] = th.R; rec[4] = th.mu1; rec[5] = th.V1;
-#pragma unroll
-                for (int k = 0; k < PP; k++) rec[6 + k] = th.B[k];
-#pragma unroll
-                for (int k = 0; k < QQ; k++) rec[6 + PP + k] = th.D[k];
-                rec[O] = cs.lik; rec[O + 1] = cs.lik1; rec[O + 2] = cs.lik2; rec[O + 3] = (double)cs.it;
-                rec[O + 4] = (double)s; rec[O + 5] = (double)cell; rec[O + 6] = (double)wit; rec[O + 7] = cs.stay ? 1.0 : 0.0;
-            }
-            const int code = __builtin_amdgcn_readfirstlane(scan_g_phase<PP, QQ, L>(wave));
-            if (code & 1) return (code & 2) != 0;
-            th.A = uniform_d(rec[0]); th.C = uniform_d(rec[1]); th.Q = uniform_d(rec[2]);
-            th.R = uniform_d(rec[3]); th.mu1 = uniform_d(rec[4]); th.V1 = uniform_d(rec[5]);
-#pragma unroll
-            for (int k = 0; k < PP; k++) th.B[k] = uniform_d(rec[6 + k]);
-#pragma unroll
-            for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(rec[6 + PP + k]);
-            cs.lik = uniform_d(rec[O]); cs.lik1 = uniform_d(rec[O + 1]); cs.lik2 = uniform_d(rec[O + 2]);
-            cs.it = __builtin_amdgcn_readfirstlane((int)rec[O + 3]);
-            wit = __builtin_amdgcn_readfirstlane((int)rec[O + 6]);
+            aborted = em_scan_steady_cell<PP, QQ, L>(prm, smem, tri, s, c0 + k, lane, nl, rp, wit);
         }
     }
 }

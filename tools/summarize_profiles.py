@@ -28,13 +28,27 @@ def counter_rows(d):
     return rows
 
 
-def per_kernel(rows, name_part):
+def base_name(n):
+    return n.replace("void ", "").split("<")[0].split("(")[0].strip()
+
+
+def em_names(kernel):
+    """Kernel-name parts that make up one EM launch: the steady form of the one-wave-per-cell kernel is
+    three launches (em_scan_kernel, em_scan_steady_kernel, em_scan_kernel): counters and times are summed
+    over them and divided by the number of steady launches."""
+    base = kernel.split("<")[0]
+    return (base, "em_scan_kernel") if base == "em_scan_steady_kernel" else (base,)
+
+
+def per_kernel(rows, names):
     agg = collections.defaultdict(list)
     disp = collections.defaultdict(set)
     for r in rows:
-        if name_part in r["Kernel_Name"]:
+        kn = base_name(r["Kernel_Name"])
+        if kn in names:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            disp[r["Counter_Name"]].add(r["Dispatch_Id"])
+            if kn == names[0]:
+                disp[r["Counter_Name"]].add(r["Dispatch_Id"])
     return {k: sum(v) / max(len(disp[k]), 1) for k, v in agg.items()}, rows
 
 
@@ -71,21 +85,29 @@ def main():
         vals = {}
         for sub in ("fetch", "write", "sq", "sq2", "sq3"):
             rows = counter_rows(os.path.join(wdir, sub))
-            v, _ = per_kernel(rows, kernel.split("<")[0])
+            v, _ = per_kernel(rows, em_names(kernel))
             vals.update(v)
             write_filtered(rows, os.path.join(prof, "%s_%s_pmc_%s.csv" % (rnd, w, sub)))
         units = bench["roofline"]["units_per_launch"]
         rocprof_ms = None
+        rocprof_parts = {}
         if stats:
+            tot_ns, calls = 0.0, 0
             for r in csv.DictReader(open(stats[0])):
-                if kernel.split("<")[0] in r["Name"]:
-                    rocprof_ms = float(r["AverageNs"]) / 1e6
+                kn = base_name(r["Name"])
+                if kn in em_names(kernel):
+                    tot_ns += float(r["TotalDurationNs"])
+                    rocprof_parts[r["Name"]] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6}
+                    if kn == em_names(kernel)[0]:
+                        calls = int(r["Calls"])
+            if calls:
+                rocprof_ms = tot_ns / calls / 1e6
         fetch, write = vals.get("FETCH_SIZE", 0.0), vals.get("WRITE_SIZE", 0.0)
         # sustained clock while the EM kernel runs: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 /
         # dispatch duration, of the timed dispatches of the sq2 pass (the first one is the warm-up)
         clocks = []
         for r in counter_rows(os.path.join(wdir, "sq2")):
-            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and kernel.split("<")[0] in r["Kernel_Name"]:
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and base_name(r["Kernel_Name"]) == kernel.split("<")[0]:
                 dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 if dur > 0:
                     clocks.append(float(r["Counter_Value"]) / 8.0 / dur)
@@ -119,6 +141,7 @@ def main():
             "lds_idx_active_cycles": vals.get("SQ_LDS_IDX_ACTIVE"),
             "sustained_clock_ghz": (sum(clocks) / len(clocks)) if clocks else None,
             "rocprof_kernel_ms": rocprof_ms,
+            "rocprof_kernels": rocprof_parts,
             "bench_kernel_ms_same_command": under["roofline"]["kernel_ms"],
             "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
             "source": ["profiles/%s_%s_%s" % (rnd, w, s) for s in
