@@ -186,10 +186,7 @@ int ldsr_em_plan(int T, int p, int q, int niter, double tol, int algo, char *buf
  * (em_pair_impl.h, LEAD).  lead_steps = -1 says the opposite: every y_t of every series is
  * observed -- AUTO then keeps the pair / quad kernels with tol > 0 as the host-pointer entries do
  * for such series (a wrong claim costs speed, not correctness: the kernels look at the mask
- * themselves).  The host-pointer entries find both facts in y.  Fully observed series of 641..1024
- * steps on the one-wave-per-cell kernel run as THREE launches (generic iterations until a cell's variance
- * recursion settles, em_scan_steady_kernel, generic iterations for cells that one gave back); the plan
- * and ldsr_last_em_kernel then name the steady kernel. */
+ * themselves).  The host-pointer entries find both facts in y. */
 int ldsr_em_batch_device_lead(int device, void *stream, int n_series, int T, int p, int q,
                               const double *d_y, const double *d_u, const double *d_v,
                               int shared_uv, const int *cell_offsets, const double *d_theta0,

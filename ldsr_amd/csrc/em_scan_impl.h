@@ -321,27 +321,6 @@ __host__ __device__ constexpr int scan_pairs(int PP, int QQ) { return (1 + PP + 
 __host__ __device__ constexpr long scan_image_doubles(int L, int W, int PP, int QQ) {
     return img_doubles(L, 64 * W, PP, QQ);
 }
-// STEADY form of the one-wave-per-cell kernel (em_scan_steady.h): fully observed series, chunks of 12..16
-// steps (T = 641..1024), in THREE launches: this kernel runs generic iterations until a cell's variance
-// recursion settles within the transient block (phase 1), em_scan_steady_kernel runs the steady iterations
-// (phase 2), this kernel again finishes the cells that one gave back (phase 3).  The first K0 = 64 / L chunks of
-// a series are its transient block, done one step per lane; their values are kept once more one step per
-// lane (`tri`, [pair][lane][2]) behind the steady kernel's image.
-#ifndef LDSR_SCAN_STEADY
-#define LDSR_SCAN_STEADY 1
-#endif
-__host__ __device__ constexpr int scan_steady_k0(int L) { return 64 / L; }
-__host__ __device__ constexpr int scan_steady_ntr(int L) { return scan_steady_k0(L) * L - 1; }
-__host__ __device__ constexpr long scan_tri_doubles(int PP, int QQ) { return (long)64 * 2 * scan_pairs(PP, QQ); }
-__host__ __device__ constexpr bool scan_steady(int PP, int QQ, int L, int W) {
-    return LDSR_SCAN_STEADY && W == 1 && L >= 12 && L <= 16 &&
-           (scan_image_doubles(L, 1, PP, QQ) + scan_tri_doubles(PP, QQ)) * 8 <= 160 * 1024;
-}
-// ... and the series long enough for a block: the first K0 lanes own L steps and there are steps behind them
-__host__ __device__ constexpr bool scan_steady_fits_T(int T, int L) {
-    return (T + L - 1) / L > scan_steady_k0(L) && T - ((T + L - 1) / L) * (L - 1) >= scan_steady_k0(L);
-}
-
 // per-wave exchange records of a multi-wave cell (doubles): forward composite (8), reverse
 // composite (4), partial sums (XCH_SUMS), plus one slot for the queue pull
 #define XCH_SUMS 40
@@ -386,50 +365,10 @@ __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_S
 // DENSE = every y_t of the series is observed: the per-step "observed ? a : b" selects vanish.
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
-// State of one cell between the launches of the steady form: a record of SCAN_CARRY_DOUBLES doubles in HBM,
-// [0] A, [1] C, [2] Q, [3] R, [4] mu1, [5] V1, [6..] B (whitened), D (whitened), then lik, lik1, lik2, it, state
-#define SCAN_CELL_DONE 0      // results stored
-#define SCAN_CELL_READY 1     // for the steady kernel
-#define SCAN_CELL_SLOW 2      // given back by the steady kernel: generic iterations to the end
-template <int PP, int QQ>
-__device__ __forceinline__ void scan_carry_store(double *rec, const Theta<PP, QQ> &th, double lik, double lik1, double lik2,
-                                                 int it, int state) {
-    constexpr int O = 6 + PP + QQ;
-    static_assert(O + 5 <= SCAN_CARRY_DOUBLES, "carry record too small");
-    rec[0] = th.A; rec[1] = th.C; rec[2] = th.Q; rec[3] = th.R; rec[4] = th.mu1; rec[5] = th.V1;
-#pragma unroll
-    for (int k = 0; k < PP; k++) rec[6 + k] = th.B[k];
-#pragma unroll
-    for (int k = 0; k < QQ; k++) rec[6 + PP + k] = th.D[k];
-    rec[O] = lik; rec[O + 1] = lik1; rec[O + 2] = lik2; rec[O + 3] = (double)it; rec[O + 4] = (double)state;
-}
-template <int PP, int QQ>
-__device__ __forceinline__ int scan_carry_state(const double *rec) {
-    return __builtin_amdgcn_readfirstlane((int)rec[6 + PP + QQ + 4]);
-}
-template <int PP, int QQ>
-__device__ __forceinline__ void scan_carry_load(const double *rec, Theta<PP, QQ> &th, double &lik, double &lik1, double &lik2,
-                                                int &it) {
-    constexpr int O = 6 + PP + QQ;
-    th.A = uniform_d(rec[0]); th.C = uniform_d(rec[1]); th.Q = uniform_d(rec[2]);
-    th.R = uniform_d(rec[3]); th.mu1 = uniform_d(rec[4]); th.V1 = uniform_d(rec[5]);
-#pragma unroll
-    for (int k = 0; k < PP; k++) th.B[k] = uniform_d(rec[6 + k]);
-#pragma unroll
-    for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(rec[6 + PP + k]);
-    lik = uniform_d(rec[O]); lik1 = uniform_d(rec[O + 1]); lik2 = uniform_d(rec[O + 2]);
-    it = __builtin_amdgcn_readfirstlane((int)rec[O + 3]);
-}
-
-// GP: a kernel with a steady form beside it -- prm.phase 1: return (state in the cell's carry record, READY) as
-// soon as the cell's variance recursion settles within the transient block; prm.phase 3: start from the carry
-// record of a cell the steady kernel gave back and run to the end
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG, bool GP = false>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
 __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp, int &wit);
-template <int L>
-__device__ __forceinline__ bool scan_steady_verdict(double V1, double A, double C, double Q, double R, int lane);
 
 // A cell the work queue handed out after the host raised the interrupt flag: not computed, but
 // marked, so that an LDSR_EINTERRUPTED return never leaves stale numbers that look like results.
@@ -463,12 +402,6 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
     const double *gimg = prm.img + (long)s * prm.img_stride;
     const double *ys;
     double *xch = nullptr;
-    // a kernel with a steady form beside it (three launches: prm.phase)
-    constexpr bool GP = scan_steady(PP, QQ, L, W) && !FIT && !GIMG;
-    if constexpr (GP) {
-        // third launch: only the cells the steady kernel gave back (uniform over the workgroup, before any barrier)
-        if (prm.phase == 3 && (prm.sc[s].n_obs != T || prm.n_slow[s] == 0)) return;
-    }
     if constexpr (GIMG) {
         ys = gimg;
         if constexpr (W > 1) xch = smem;
@@ -486,7 +419,6 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
     // nothing more and marks whatever the queue still hands it.
     int wit = 0;
     bool aborted = false;
-    if constexpr (GP) { if (prm.phase == 3) wit = 63; }     // (poll at once: an earlier launch may have seen the flag)
     if constexpr (W > 1) {
         // one group: every wave of the workgroup works on the same cell
         int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
@@ -506,7 +438,7 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
     } else if constexpr (!QUEUE) {
         if (wave >= nc) return;   // whole wave leaves; no barrier follows
         if (dense)
-            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG, GP>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
+            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
         else
             em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
     } else {
@@ -520,19 +452,9 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
             if (lane == 0) k = atomicAdd(prm.queue + s, 1);
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= nc) break;
-            if (aborted) {
-                if constexpr (GP) {
-                    if (prm.phase != 0) {      // (three launches: only the cells that are this launch's)
-                        double *rec = prm.carry + (long)(c0 + k) * SCAN_CARRY_DOUBLES;
-                        if (prm.phase == 3 && scan_carry_state<PP, QQ>(rec) != SCAN_CELL_SLOW) continue;
-                        if (lane == 0) rec[6 + PP + QQ + 4] = (double)SCAN_CELL_DONE;
-                    }
-                }
-                if (lane == 0) mark_cell_interrupted(prm, c0 + k);
-                continue;
-            }
+            if (aborted) { if (lane == 0) mark_cell_interrupted(prm, c0 + k); continue; }
             if (dense)
-                aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG, GP>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
+                aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
             else
                 aborted = em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
         }
@@ -550,15 +472,22 @@ __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(
         last_ = now_;                                                         \
         __builtin_amdgcn_sched_barrier(0);                                    \
     }
+#elif defined(LDSR_SCAN_MARK)
+// (compile-only: section boundaries as comments in the listing, for instruction counts per section)
+#define SCAN_TICK(k)                                                          \
+    {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        asm volatile("; SECTION_MARK " #k);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
 #else
 #define SCAN_TICK(k)
 #endif
 
-template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG, bool GP>
+template <int PP, int QQ, int L, int W, bool DENSE, bool FIT, bool GIMG>
 __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *ys,
                                              __amdgpu_buffer_rsrc_t rs, double *xch,
                                              int s, int cell, int lane, int wv, int nl, int rp, int &wit) {
-    static_assert(!GP || (DENSE && W == 1 && !FIT && !GIMG), "steady form beside it: fully observed series, one wave per cell, LDS image");
     constexpr int NL = 64 * W;
     constexpr bool EBR = scan_ebr(PP, QQ);    // e_t, B u_t stay in registers from F1 to F2
     constexpr bool SB = scan_sb(PP, QQ);
@@ -611,20 +540,8 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     }
 
     Theta<PP, QQ> th;
-    double lik = NAN, lik1 = NAN, lik2 = NAN;
-    int it = 0;
-    double *rec = nullptr;            // the cell's carry record (steady form in three launches)
-    bool resumed = false;
-    if constexpr (GP) {
-        if (prm.phase != 0) rec = prm.carry + (long)cell * SCAN_CARRY_DOUBLES;
-        if (prm.phase == 3) {
-            if (scan_carry_state<PP, QQ>(rec) != SCAN_CELL_SLOW) return false;
-            scan_carry_load<PP, QQ>(rec, th, lik, lik1, lik2, it);
-            resumed = true;
-        }
-    }
-    if (!resumed) load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
-    if (!resumed && sc->status != 0) {     // uniform over the cell's waves: no barrier is skipped unevenly
+    load_theta(th, prm.theta0 + (long)cell * P, prm.p, prm.q, prm.has_u, prm.has_v);
+    if (sc->status != 0) {     // uniform over the cell's waves: no barrier is skipped unevenly
         if (lane == 0 && wv == 0) {
             if constexpr (!FIT) {
                 for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
@@ -635,7 +552,6 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             prm.lik[cell] = NAN;
             prm.status[cell] = 2;
             if (FIT && prm.pen) prm.pen[cell] = NAN;
-            if (GP && rec) rec[6 + PP + QQ + 4] = (double)SCAN_CELL_DONE;
         }
         if constexpr (FIT) {
             if (act)
@@ -651,22 +567,9 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         return false;
     }
 
-    if (!resumed) white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
-    if constexpr (GP) {
-        // first launch: a cell whose variance recursion settles within the block at theta0 is the steady kernel's at once
-        if (prm.phase == 1) {
-            th.A = uniform_d(th.A); th.C = uniform_d(th.C); th.Q = uniform_d(th.Q);
-            th.R = uniform_d(th.R); th.mu1 = uniform_d(th.mu1); th.V1 = uniform_d(th.V1);
-#pragma unroll
-            for (int k = 0; k < PP; k++) th.B[k] = uniform_d(th.B[k]);
-#pragma unroll
-            for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
-            if (scan_steady_verdict<L>(th.V1, th.A, th.C, th.Q, th.R, lane)) {
-                if (lane == 0) scan_carry_store<PP, QQ>(rec, th, lik, lik1, lik2, it, SCAN_CELL_READY);
-                return false;
-            }
-        }
-    }
+    white_in(th, (SeriesConstK)sc);   // (B, D) -> whitened input coordinates (mstep_update_white)
+    double lik = NAN, lik1 = NAN, lik2 = NAN;
+    int it = 0;
     bool interrupted = false;   // the host raised the interrupt flag (src/EM.cpp:261-262 polls too)
     // Per-step (J_t, g_t, h_t) kept in registers between the forward and the backward sweep.
     // Chunks longer than 16 steps (T > 1024) would need more than 256 VGPRs and drop to one
@@ -1229,15 +1132,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < PP; k++) th.B[k] = uniform_d(th.B[k]);
 #pragma unroll
         for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
-        if constexpr (GP) {
-            // first launch: over to the steady kernel as soon as the variance recursion settles within the block
-            if (prm.phase == 1 && scan_steady_verdict<L>(th.V1, th.A, th.C, th.Q, th.R, lane)) {
-                if (lane == 0) scan_carry_store<PP, QQ>(rec, th, lik, lik1, lik2, it, SCAN_CELL_READY);
-                return false;
-            }
-        }
     }
-    if (GP && rec && lane == 0) rec[6 + PP + QQ + 4] = (double)SCAN_CELL_DONE;
 
     if (lane == 0 && wv == 0) {
         if constexpr (!FIT) {
@@ -1268,8 +1163,6 @@ __host__ __device__ constexpr bool scan_uses_gimg(int L, int W, int PP, int QQ) 
     return L >= 20 && (W > 1 || !scan_image_fits_lds(L, W, PP, QQ));
 }
 
-#include "em_scan_steady.h"
-
 // Launch plan of a (T, PP, QQ) shape: chunk length, waves per cell, cells per workgroup, and
 // whether the series image is read from global memory (kernels_scan.hip).
 struct ScanPlan {
@@ -1283,6 +1176,3 @@ ScanPlan scan_plan(int T, int PP, int QQ);
 template <int L, int W>
 hipError_t launch_em_scan_LW(const EmParams &prm, int PPv, int QQv, int n_blocks, int cpb,
                              bool queue, bool gimg, bool fit, hipStream_t stream);
-template <int L>
-hipError_t launch_em_scan_steady_L(const EmParams &prm, int PPv, int QQv, int n_blocks, int cpb, bool queue,
-                                   hipStream_t stream);

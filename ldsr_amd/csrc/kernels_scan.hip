@@ -92,28 +92,6 @@ hipError_t launch_em_scan(const EmParams &prm, int PP, int QQ, int n_blocks, boo
 #undef CASE_LW
 }
 
-// ---- steady form of the one-wave-per-cell kernel (em_scan_steady.h): the member's second kernel
-bool em_scan_steady_supported(int T, int PP, int QQ) {
-    const ScanPlan p = scan_plan(T, PP, QQ);
-    return p.ok && !p.gimg && scan_steady(PP, QQ, p.L, p.W) && scan_steady_fits_T(T, p.L);
-}
-void em_scan_steady_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len) {
-    const ScanPlan p = scan_plan(T, PP, QQ);
-    snprintf(buf, len, "em_scan_steady_kernel<%d, %d, %d, %s>", PP, QQ, p.L, queue ? "true" : "false");
-}
-hipError_t launch_em_scan_steady(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue, hipStream_t stream) {
-    const ScanPlan p = scan_plan(prm.T, PP, QQ);
-    if (!em_scan_steady_supported(prm.T, PP, QQ)) return hipErrorInvalidValue;
-    switch (p.L) {
-        case 12: return launch_em_scan_steady_L<12>(prm, PP, QQ, n_blocks, p.cpb, queue, stream);
-        case 13: return launch_em_scan_steady_L<13>(prm, PP, QQ, n_blocks, p.cpb, queue, stream);
-        case 14: return launch_em_scan_steady_L<14>(prm, PP, QQ, n_blocks, p.cpb, queue, stream);
-        case 15: return launch_em_scan_steady_L<15>(prm, PP, QQ, n_blocks, p.cpb, queue, stream);
-        case 16: return launch_em_scan_steady_L<16>(prm, PP, QQ, n_blocks, p.cpb, queue, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
-
 // ---- two / four cells per wave (em_pair_impl.h) --------------------------------------------------
 // lpc = lanes per cell: 32 (two cells per wave, T <= 1024) or 16 (four, T <= 512).
 // Smallest chunk length with L (L-1) <= T <= lpc L.  The kernel pays off only with two waves per
@@ -221,11 +199,6 @@ void em_kernel_inventory(std::string &out) {
                 };
                 if (gimg) { add(true, true, false); add(false, true, true); }
                 if (lds) { add(false, false, false); add(true, false, false); add(false, false, true); }
-                if (lds && scan_steady(PP, QQ, L, W))
-                    for (int q = 0; q < 2; q++) {
-                        snprintf(buf, sizeof(buf), "em_scan_steady_kernel<%d, %d, %d, %s>\n", PP, QQ, L, q ? "true" : "false");
-                        out += buf;
-                    }
             }
     };
     for (int L : Ls1) scan_names(L, 1);

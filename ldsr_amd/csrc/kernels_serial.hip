@@ -232,9 +232,7 @@ __global__ __launch_bounds__(1024) void series_prep_kernel(PrepParams prm) {
     __shared__ SeriesConst sc;
     __shared__ double inv_ws[LDSR_MAXPQ * LDSR_MAXPQ];
 
-    // (queue heads of up to three EM launches -- the steady form of the scan kernel -- and the series' count of
-    // cells its steady kernel gave back)
-    if (tid < 4 && prm.queue) prm.queue[tid * prm.n_series + s] = 0;
+    if (tid == 0 && prm.queue) prm.queue[s] = 0;
     // prepared copies
     for (int t = tid; t < T; t += NT) {
         const double yv = y[t];

@@ -430,12 +430,6 @@ static bool order_enabled() {
     return on;
 }
 
-// LDSR_SCAN_STEADY=0: fully observed series take the generic sweeps in the one-wave-per-cell kernel, one launch (A/B runs)
-static bool scan_steady_enabled() {
-    static const bool on = [] { const char *e = getenv("LDSR_SCAN_STEADY"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 static bool pair_enabled() {
     static const bool on = [] { const char *e = getenv("LDSR_PAIR"); return !(e && e[0] == '0'); }();
     return on;
@@ -465,7 +459,7 @@ static int cells_per_block(int algo, int T, int PP, int QQ, int lpc = 32, int le
 }
 
 struct WsLayout {
-    size_t sc, yp, yz, up, vp, img, img2, img3, blk, soc, queue, perm, perm_key, carry, scratch, total;
+    size_t sc, yp, yz, up, vp, img, img2, img3, blk, soc, queue, perm, perm_key, scratch, total;
     long scratch_stride, img_stride;   // img_stride: doubles per series image (0 = no image)
     long img2_stride;                  // pair kernel's image (0 = none)
     long img3_stride;                  // ... and its lead image
@@ -508,14 +502,11 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     // (block table, then the device copy of the cell offsets for series_prep's cell ordering)
     L.blk = o; o = align256(o + sizeof(int) * (3 * (size_t)L.max_blocks + (size_t)n_series + 1));
     L.soc = o; o = align256(o + sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1));
-    L.queue = o; o = align256(o + sizeof(int) * 4 * (size_t)n_series);
+    L.queue = o; o = align256(o + sizeof(int) * (size_t)n_series);
     // cell order of the pair kernel's steady form (two cells per wave, narrow inputs): position -> cell, and the keys
     const bool may_order = PP <= 4 && QQ <= 4 && algo != LDSR_ALGO_SERIAL;
     L.perm = o; o = align256(o + (may_order ? sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1) : 0));
     L.perm_key = o; o = align256(o + (may_order ? sizeof(int) * (size_t)(n_cells > 0 ? n_cells : 1) : 0));
-    // carry records of the scan kernel's steady form (three launches: em_scan_steady.h)
-    const bool may_carry = algo != LDSR_ALGO_SERIAL && em_scan_steady_supported(T, PP, QQ);
-    L.carry = o; o = align256(o + (may_carry ? sizeof(double) * SCAN_CARRY_DOUBLES * (size_t)(n_cells > 0 ? n_cells : 1) : 0));
     L.scratch_stride = ((long)n_cells + 63) / 64 * 64;
     L.scratch = o;
     if (algo == LDSR_ALGO_SERIAL) o = align256(o + sizeof(double) * 2 * (size_t)T * L.scratch_stride);
@@ -664,10 +655,7 @@ static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, ch
     if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
-        // (fully observed series, chunks of 12..16 steps: the steady kernel between two launches of the generic one)
-        if (fully_observed && scan_steady_enabled() && em_scan_steady_supported(T, PP, QQ)) {
-            if (buf && len) em_scan_steady_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), buf, len);
-        } else if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
+        if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
     } else if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
         // AUTO (a launch that fills the device assumed): four cells per wave where they fit, else two
         int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
@@ -926,18 +914,6 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.n_iter = d_n_iter; prm.status = d_status;
     prm.queue = (int *)(ws + L.queue);
     prm.perm = steady_launch ? (const int *)(ws + L.perm) : nullptr;
-    // Steady form of the one-wave-per-cell kernel: three launches (em_scan_steady.h).  The kernels look at
-    // every series themselves (fully observed or not); a caller that knows there is a missing y_t says so and
-    // gets the one launch.
-    const bool steady3 = algo == LDSR_ALGO_SCAN && scan_steady_enabled() && dense_hint != 0 && algo_layout != LDSR_ALGO_SERIAL &&
-                         em_scan_steady_supported(T, PP, QQ);
-    prm.phase = steady3 ? 1 : 0;
-    prm.carry = (double *)(ws + L.carry);
-    prm.n_slow = (int *)(ws + L.queue) + 3 * (size_t)n_series;
-    {   // (test hook, read per call: every cell goes through the give-back path at that iteration)
-        const char *e = getenv("LDSR_SCAN_GIVEBACK");
-        prm.giveback_it = e ? atoi(e) : -1;
-    }
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
     int slot;
@@ -945,23 +921,15 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     {
         char nm[160];
         if (cpw) em_pair_kernel_name(Te, PP, QQ, lpc, use_queue, nm, sizeof(nm), lead > 0);
-        // (three launches: the steady kernel does the work when the series are fully observed -- named when the caller said so)
-        else if (steady3 && dense_hint == 1) em_scan_steady_kernel_name(T, PP, QQ, use_queue, nm, sizeof(nm));
         else if (algo == LDSR_ALGO_SCAN) em_scan_kernel_name(T, PP, QQ, use_queue, false, nm, sizeof(nm));
         else em_serial_kernel_name(T, PP, QQ, nm, sizeof(nm));
         remember_kernel(device, nm);
     }
     if (cpw)
         HIPCHK(launch_em_pair(prm, PP, QQ, lpc, n_blocks, use_queue, stream));
-    else if (algo == LDSR_ALGO_SCAN) {
+    else if (algo == LDSR_ALGO_SCAN)
         HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
-        if (steady3) {
-            prm.phase = 2; prm.queue = (int *)(ws + L.queue) + (size_t)n_series;
-            HIPCHK(launch_em_scan_steady(prm, PP, QQ, n_blocks, use_queue, stream));
-            prm.phase = 3; prm.queue = (int *)(ws + L.queue) + 2 * (size_t)n_series;
-            HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
-        }
-    } else
+    else
         HIPCHK(launch_em_serial(prm, PP, QQ, n_blocks, stream));
     HIPCHK(prof_end(stream, slot));
     return LDSR_OK;

@@ -289,8 +289,6 @@ __device__ __forceinline__ void white_out(Theta<PP, QQ> &th, SCP sc) {
 }
 
 // Kernel argument block shared by the EM kernels.
-#define SCAN_CARRY_DOUBLES 32     // a cell's record between the launches of the scan kernel's steady form
-
 struct EmParams {
     int T, p, q, has_u, has_v, niter, n_cells;
     int liks_nanfill;        // pad liks[cell][n_iter..niter) with NaN (the batch ABI); 0 = leave as is
@@ -311,13 +309,6 @@ struct EmParams {
     const int *blk_series, *blk_cell0, *blk_ncell;  // block table
     int *queue;              // scan kernel: per-series cell counter (zeroed by series_prep_kernel)
     const int *perm;         // pair kernel, steady form: position -> cell (slowest cells first), or null
-    // scan kernel, steady form in three launches (em_scan_steady.h): 0 = the whole run in one launch; 1 = generic
-    // iterations until the cell's variance recursion settles within the transient block (state to `carry`);
-    // 2 = the steady kernel; 3 = generic iterations to the end for the cells the steady kernel gave back
-    int phase;
-    double *carry;           // [n_cells][SCAN_CARRY_DOUBLES]: a cell's state between those launches
-    int *n_slow;             // [n_series]: cells of the series the steady kernel gave back (zeroed by series_prep_kernel)
-    int giveback_it;         // test hook (LDSR_SCAN_GIVEBACK=k): the steady kernel gives every cell back at iteration k; -1 = off
     const double *theta0;    // [n_cells][6+p+q]
     double *theta, *lik, *liks;
     int *n_iter, *status;

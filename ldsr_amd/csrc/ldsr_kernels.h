@@ -19,7 +19,7 @@ struct PrepParams {
     double *img3;             // ... and img3 the (whitened) u_t of the lead, [step of the lane][NL2 lanes][PP], or null
     long img3_stride;
     SeriesConst *sc;
-    int *queue;               // [4][n_series] work-queue heads of up to three EM launches + the steady form's give-back counts, reset to 0 here
+    int *queue;               // [n_series] work-queue heads, reset to 0 here
     // Cell order of the pair kernel's steady form (em_pair_impl.h em_pair_body_steady): n_series more
     // workgroups sort every series' cells by the predicted number of steps its variance recursion needs
     // to settle at theta0, slowest first -- perm[position] = cell.  Null: no ordering.
@@ -93,10 +93,6 @@ hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_bl
 void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead = false);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
-// steady form of the one-wave-per-cell kernel: the second of three launches (em_scan_steady.h)
-bool em_scan_steady_supported(int T, int PP, int QQ);
-void em_scan_steady_kernel_name(int T, int PP, int QQ, bool queue, char *buf, size_t len);
-hipError_t launch_em_scan_steady(const EmParams &prm, int PP, int QQ, int n_blocks, bool queue, hipStream_t stream);
 void em_serial_kernel_name(int T, int PP, int QQ, char *buf, size_t len);
 #include <string>
 void em_kernel_inventory(std::string &out);      // names of every compiled scan / pair instantiation, one per line

@@ -25,4 +25,6 @@ python3 bench.py --workload cfg3 --mask paleo --steps 20 --warmup 3 --no-cpu-bas
 python3 bench.py --workload cfg3 --niter 1000 --tol 1e-5 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry > $x/cfg3_conv_bench.json 2>> $x/err
 python3 bench.py --workload cfg4 --niter 1000 --tol 1e-5 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry > $x/cfg4_conv_bench.json 2>> $x/err
 python3 bench.py --workload cfg5 --niter 1000 --tol 1e-5 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry > $x/cfg5_conv_bench.json 2>> $x/err
+# the line the round driver records (`python bench.py`, defaults: cpu_baseline and host_entry included)
+python3 bench.py > $x/cfg2_full_bench.json 2>> $x/err
 echo "extra done: $(ls $x)"

@@ -21,34 +21,29 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(files):
+    """gpurun merges a call's output into the local gpurun_out/: a tag used twice leaves two runs' files side
+    by side (rocprofv3 prefixes them with the pid).  Only the newest run counts."""
+    if not files:
+        return files
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if t - os.path.getmtime(f) < 30]
+
+
 def counter_rows(d):
     rows = []
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))):
         rows += list(csv.DictReader(open(f)))
     return rows
 
 
-def base_name(n):
-    return n.replace("void ", "").split("<")[0].split("(")[0].strip()
-
-
-def em_names(kernel):
-    """Kernel-name parts that make up one EM launch: the steady form of the one-wave-per-cell kernel is
-    three launches (em_scan_kernel, em_scan_steady_kernel, em_scan_kernel): counters and times are summed
-    over them and divided by the number of steady launches."""
-    base = kernel.split("<")[0]
-    return (base, "em_scan_kernel") if base == "em_scan_steady_kernel" else (base,)
-
-
-def per_kernel(rows, names):
+def per_kernel(rows, name_part):
     agg = collections.defaultdict(list)
     disp = collections.defaultdict(set)
     for r in rows:
-        kn = base_name(r["Kernel_Name"])
-        if kn in names:
+        if name_part in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            if kn == names[0]:
-                disp[r["Counter_Name"]].add(r["Dispatch_Id"])
+            disp[r["Counter_Name"]].add(r["Dispatch_Id"])
     return {k: sum(v) / max(len(disp[k]), 1) for k, v in agg.items()}, rows
 
 
@@ -77,7 +72,7 @@ def main():
         bench = json.loads(open(os.path.join(wdir, "bench.json")).read().strip().splitlines()[-1])
         under = json.loads(open(os.path.join(wdir, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
         kernel = bench["roofline"]["kernel"]
-        stats = glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_stats.csv"))
+        stats = newest(glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_stats.csv")))
         if stats:
             shutil.copy(stats[0], os.path.join(prof, "%s_%s_kernel_stats.csv" % (rnd, w)))
         json.dump(bench, open(os.path.join(prof, "%s_%s_bench.json" % (rnd, w)), "w"))
@@ -85,29 +80,21 @@ def main():
         vals = {}
         for sub in ("fetch", "write", "sq", "sq2", "sq3"):
             rows = counter_rows(os.path.join(wdir, sub))
-            v, _ = per_kernel(rows, em_names(kernel))
+            v, _ = per_kernel(rows, kernel.split("<")[0])
             vals.update(v)
             write_filtered(rows, os.path.join(prof, "%s_%s_pmc_%s.csv" % (rnd, w, sub)))
         units = bench["roofline"]["units_per_launch"]
         rocprof_ms = None
-        rocprof_parts = {}
         if stats:
-            tot_ns, calls = 0.0, 0
             for r in csv.DictReader(open(stats[0])):
-                kn = base_name(r["Name"])
-                if kn in em_names(kernel):
-                    tot_ns += float(r["TotalDurationNs"])
-                    rocprof_parts[r["Name"]] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6}
-                    if kn == em_names(kernel)[0]:
-                        calls = int(r["Calls"])
-            if calls:
-                rocprof_ms = tot_ns / calls / 1e6
+                if kernel.split("<")[0] in r["Name"]:
+                    rocprof_ms = float(r["AverageNs"]) / 1e6
         fetch, write = vals.get("FETCH_SIZE", 0.0), vals.get("WRITE_SIZE", 0.0)
         # sustained clock while the EM kernel runs: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 /
         # dispatch duration, of the timed dispatches of the sq2 pass (the first one is the warm-up)
         clocks = []
         for r in counter_rows(os.path.join(wdir, "sq2")):
-            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and base_name(r["Kernel_Name"]) == kernel.split("<")[0]:
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and kernel.split("<")[0] in r["Kernel_Name"]:
                 dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 if dur > 0:
                     clocks.append(float(r["Counter_Value"]) / 8.0 / dur)
@@ -141,7 +128,6 @@ def main():
             "lds_idx_active_cycles": vals.get("SQ_LDS_IDX_ACTIVE"),
             "sustained_clock_ghz": (sum(clocks) / len(clocks)) if clocks else None,
             "rocprof_kernel_ms": rocprof_ms,
-            "rocprof_kernels": rocprof_parts,
             "bench_kernel_ms_same_command": under["roofline"]["kernel_ms"],
             "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
             "source": ["profiles/%s_%s_%s" % (rnd, w, s) for s in
