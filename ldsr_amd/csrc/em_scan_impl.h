@@ -358,7 +358,21 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_SCAN_PREFETCH   // one-step software pipeline of the LDS reads in the long-chunk sweeps
 #define LDSR_SCAN_PREFETCH 0  // (same-box A/B on cfg4: 10.72 ms with, 10.40 ms without -- off)
 #endif
+#ifndef LDSR_SCAN_SPF        // short chunks: the image reads of F1 / B2 run a step or two ahead of their use
+#define LDSR_SCAN_SPF 1
+#endif
+#ifndef LDSR_SCAN_SPF_MAXPQ  // widest padded p + q that takes the read-ahead at every chunk length (register budget: two
+#define LDSR_SCAN_SPF_MAXPQ 8 // waves per SIMD); wider inputs -- the ring is ~50 VGPRs there -- only with chunks of <= 4 steps
+#endif
 __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_OCC1 && PP + QQ >= 12; }
+// Read-ahead of the LDS image in the short-chunk sweeps (em_scan_cell: SPF).  Left alone the scheduler issues
+// every ds_read_b128 right before its use and waits for it: with two waves per SIMD the other wave covers
+// that, a LONE wave -- the reference's own call shape, LDS_reconstruction(num.restarts = 50): 50 waves on
+// 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3: 4015 +
+// 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).
+__host__ __device__ constexpr bool scan_spf(int PP, int QQ, int L, int W) {
+    return LDSR_SCAN_SPF && W == 1 && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= 16 : L <= 4);
+}
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
 
@@ -518,6 +532,27 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     auto Yat = [&](int j) { return val(j, 0); };
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
+    // SPF: the K values of a step are read SPFD steps ahead of their use into an explicit register ring pinned by
+    // scheduling barriers (the full pairs of step j in slot j % SPFD; the odd value of an odd K comes in ONE
+    // ds_read_b128 for the two steps 2 jj, 2 jj + 1 that share its pair: slot jj & 1).
+    constexpr bool SPF = scan_spf(PP, QQ, L, W) && !GIMG && !scan_ebr(PP, QQ);
+    constexpr int SPFD = scan_pairs(PP, QQ) <= 2 ? 2 : 1;
+    constexpr int KH2 = 2 * (KV / 2);              // values held in full pairs
+    constexpr bool KODD = (KV & 1) != 0;
+    constexpr int SPFN = SPFD + 1;                 // ring slots: step j is used while steps j+1 .. j+SPFD are in flight
+    struct StepRing {
+        double w[SPFN][KH2 > 0 ? KH2 : 1];
+        double t[KH2 > 0 ? KH2 : 1];               // the predicated step L-1 (reverse sweeps)
+        double o[2][2];
+    };
+    auto ring_rd = [&](double (&w)[KH2 > 0 ? KH2 : 1], double (&o)[2][2], int jn, bool with_odd) {
+#pragma unroll
+        for (int i = 0; i < KH2; i++) w[i] = val(jn, i);
+        if (KODD && with_odd) {
+            o[(jn >> 1) & 1][0] = val(jn & ~1, KV - 1);
+            o[(jn >> 1) & 1][1] = val(jn | 1, KV - 1);
+        }
+    };
     const int T = prm.T;
     const int P = 6 + prm.p + prm.q;
     const SeriesConst *__restrict__ sc = prm.sc + s;
@@ -616,12 +651,29 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             return bu;
         };
 
+        // ... and the same from a step's values held in registers (SPF): value i of step j
+        auto e_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
+            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+            double e = vv(0);
+#pragma unroll
+            for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vv(1 + PP + k), e);
+            return e;
+        };
+        auto bu_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
+            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+            double bu = 0.0;
+#pragma unroll
+            for (int k = 0; k < PP; k++) bu = fma(th.B[k], vv(1 + k), bu);
+            return bu;
+        };
+
         // ------------------------------------------------ F1: compose this lane's step matrices
         PMat M;
         M.m00 = 1.0; M.m01 = 0.0; M.m10 = 0.0; M.m11 = 1.0; M.m20 = 0.0; M.m21 = 0.0; M.m22 = 1.0;
-        auto f1 = [&](int j) {
+        double eT = 0.0, buT = 0.0;      // SPF: e_t, B u_t of the predicated step L-1, kept for F2
+        auto f1c = [&](int j, double e, double bu) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            const double e = e_at(j), bu = bu_at(j);
+            if (SPF && j == L - 1) { eT = e; buT = bu; }
             if constexpr (EBR) { ev[j] = e; buv[j] = bu; }
             if (EBA && j < L - 1) { gv_[j] = e; hv[j] = bu; }   // (the predicated L-th step re-reads)
             const double a00 = o ? alpha : A2;
@@ -635,6 +687,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
             if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
         };
+        auto f1 = [&](int j) { f1c(j, e_at(j), bu_at(j)); };
         if constexpr (DENSE && L <= 16 && PP <= LDSR_DENSE_F1_POW_MAXP && QQ <= LDSR_DENSE_F1_POW_MAXQ && LDSR_DENSE_F1_POW) {
             // Fully observed series: every step has the SAME 2x2 block Bm = [[alpha, Q],[C2R, 1]],
             // so the chunk's 2x2 block is a power of it -- lane independent, by binary
@@ -670,19 +723,40 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             if (act) {
                 // row of the last step (lanes with the L-th step), else the identity row
                 double ra = 0.0, rb = 0.0, rc = 1.0;
-                if (tail) {
-                    const double e = e_at(L - 1), bu = bu_at(L - 1);
-                    ra = fma(bu, C2R, ACR * e); rb = bu; rc = A;
-                }
-#pragma unroll
-                for (int j = L - 2; j >= 0; j--) {
-                    const double e = e_at(j), bu = bu_at(j);
+                auto row_step = [&](int j, double e, double bu) {
                     if constexpr (EBA) { gv_[j] = e; hv[j] = bu; }
                     const double s20 = fma(bu, C2R, ACR * e);
                     const double na = fma(ra, alpha, fma(rb, C2R, rc * s20));
                     rb = fma(ra, Q, fma(rc, bu, rb));
                     ra = na;
                     rc *= A;
+                };
+                if constexpr (SPF) {
+                    // steps L-1 (predicated), L-2, ... 0: the reads run SPFD steps ahead
+                    StepRing r;
+                    ring_rd(r.t, r.o, L - 1, true);
+#pragma unroll
+                    for (int d = 0; d < SPFD; d++)
+                        if (L - 2 - d >= 0) ring_rd(r.w[(L - 2 - d) % SPFN], r.o, L - 2 - d, ((L - 2 - d) & 1) != 0);
+                    __builtin_amdgcn_sched_barrier(0x6);
+                    if (tail) {
+                        const double e = e_of(r.t, r.o, L - 1), bu = bu_of(r.t, r.o, L - 1);
+                        eT = e; buT = bu;
+                        ra = fma(bu, C2R, ACR * e); rb = bu; rc = A;
+                    }
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) {
+                        if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                        row_step(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                        __builtin_amdgcn_sched_barrier(0x6);
+                    }
+                } else {
+                    if (tail) {
+                        const double e = e_at(L - 1), bu = bu_at(L - 1);
+                        ra = fma(bu, C2R, ACR * e); rb = bu; rc = A;
+                    }
+#pragma unroll
+                    for (int j = L - 2; j >= 0; j--) row_step(j, e_at(j), bu_at(j));
                 }
                 M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
                 M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
@@ -690,7 +764,21 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                 prenorm(M);
             }
         } else if (act) {
-            if (L <= 16 || EBR) {
+            if constexpr (SPF) {
+                // steps 0 .. L-2, then the predicated step L-1: the reads run SPFD steps ahead
+                StepRing r;
+#pragma unroll
+                for (int d = 0; d < SPFD; d++)
+                    if (d <= L - 1) ring_rd(r.w[d % SPFN], r.o, d, (d & 1) == 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) {
+                    if (j + SPFD <= L - 1) ring_rd(r.w[(j + SPFD) % SPFN], r.o, j + SPFD, ((j + SPFD) & 1) == 0);
+                    f1c(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+                if (tail) f1c(L - 1, e_of(r.w[(L - 1) % SPFN], r.o, L - 1), bu_of(r.w[(L - 1) % SPFN], r.o, L - 1));
+            } else if (L <= 16 || EBR) {
 #pragma unroll
                 for (int j = 0; j < L - 1; j++) f1(j);
             } else {           // no register arrays here: keep long chunks rolled (code size, VGPRs)
@@ -698,7 +786,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
 #pragma unroll 4
                 for (int j = 1; j < L - 1; j++) f1(j);
             }
-            if (tail) f1(L - 1);
+            if (!SPF && tail) f1(L - 1);
             prenorm(M);
         }
 
@@ -785,6 +873,8 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                 if (j + 1 < L) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
             } else if (EBA && j < L - 1) {
                 e = gv_[j]; bu = hv[j];                // left there by F1; overwritten below by g_t, h_t
+            } else if (SPF) {
+                e = eT; bu = buT;                      // (the predicated step: kept by F1)
             } else {
                 e = EBR ? ev[j] : e_at(j);
                 bu = EBR ? buv[j] : bu_at(j);
@@ -937,7 +1027,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             Xn = Xs;
             Vn = Vs;
         };
-        auto b2b = [&](int j, int i, bool top) {   // j = step in the chunk, i = storage index
+        auto b2b_v = [&](int j, int i, bool top, auto &&vv) {   // j = step in the chunk, i = storage index, vv(k) = value k of the step
             const bool o = DENSE || ((obsmask >> j) & 1u);
             const double J = Jv[i], Xs = gv_[i], Vs = hv[i];
             const double Xnx = top ? XnE : gv_[top ? i : i + 1];
@@ -946,7 +1036,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             double bu = 0.0;
 #pragma unroll
             for (int k = 0; k < PP; k++) {
-                const double ut = Uat(j, k);                      // zero at t = T-1
+                const double ut = vv(1 + k);                      // zero at t = T-1
                 aTx1u[k] = fma(Xnx, ut, aTx1u[k]);                // :190
                 aTux[k] = fma(ut, Xs, aTux[k]);                   // :191
                 if (FIT) bu = fma(th.B[k], ut, bu);
@@ -954,12 +1044,12 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             term = fma(Xs, Xs, Vs);
             aPall += term;                                        // :181,:183
             const double xo = o ? Xs : 0.0;
-            aSyx = fma(Yat(j), xo, aSyx);                         // :151
+            aSyx = fma(vv(0), xo, aSyx);                          // :151
             if (!DENSE) aSxx += o ? term : 0.0;                   // :152
             double dv = 0.0;
 #pragma unroll
             for (int k = 0; k < QQ; k++) {
-                const double vt = Vat(j, k);
+                const double vt = vv(1 + PP + k);
                 aSxv[k] = fma(xo, vt, aSxv[k]);                   // :159
                 if (FIT) dv = fma(th.D[k], vt, dv);
             }
@@ -977,14 +1067,38 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             }
             if ((L > 16 && (j & 3) == 3) || SB) __builtin_amdgcn_sched_barrier(0);
         };
+        auto b2b = [&](int j, int i, bool top) { b2b_v(j, i, top, [&](int k) { return val(j, k); }); };
         if (act) {
-            if (tail) b2a(NS - 1);
-            else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }  // "next" of step L-2 for short chunks
+            if constexpr (SPF) {
+                // pass 2 reads the image again, last step first: the first reads are issued ahead of pass 1
+                static_assert(HS == 0, "short chunks only");
+                StepRing r;
+                ring_rd(r.t, r.o, L - 1, true);
 #pragma unroll
-            for (int i = NS - 2; i >= 0; i--) b2a(i);
-            if (tail) b2b(L - 1, NS - 1, true);
+                for (int d = 0; d < SPFD; d++)
+                    if (L - 2 - d >= 0) ring_rd(r.w[(L - 2 - d) % SPFN], r.o, L - 2 - d, ((L - 2 - d) & 1) != 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+                if (tail) b2a(NS - 1);
+                else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }
 #pragma unroll
-            for (int i = NS - 2; i >= 0; i--) b2b(HS + i, i, false);
+                for (int i = NS - 2; i >= 0; i--) b2a(i);
+                __builtin_amdgcn_sched_barrier(0x6);
+                if (tail) b2b_v(L - 1, NS - 1, true, [&](int k) { return k < KH2 ? r.t[k] : r.o[((L - 1) >> 1) & 1][(L - 1) & 1]; });
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) {
+                    if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                    b2b_v(j, j, false, [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; });
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            } else {
+                if (tail) b2a(NS - 1);
+                else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }  // "next" of step L-2 for short chunks
+#pragma unroll
+                for (int i = NS - 2; i >= 0; i--) b2a(i);
+                if (tail) b2b(L - 1, NS - 1, true);
+#pragma unroll
+                for (int i = NS - 2; i >= 0; i--) b2b(HS + i, i, false);
+            }
         }
         if (HS > 0) {
             // re-run the forward recursion of steps [0, HS) from the lane's entry state; the

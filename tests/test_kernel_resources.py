@@ -25,15 +25,49 @@ def test_scan_kernel_register_budget():
         return vgpr, vspill, scratch, occ
 
     for tmpl in ("<1, 2, 16, 1, false, false, false>", "<1, 2, 16, 1, true, false, false>",
-                 "<1, 4, 16, 1, false, false, false>", "<1, 1, 16, 1, false, false, false>",
-                 "<2, 2, 16, 1, false, false, false>"):
+                 "<1, 4, 16, 1, false, false, false>", "<1, 1, 16, 1, false, false, false>"):
         vgpr, vspill, scratch, occ = get(tmpl)
         assert (vspill, scratch, occ) == (0, 0, 2) and vgpr <= 256, (tmpl, vgpr, vspill, scratch, occ)
+    # (2,2) and (4,4): with the read-ahead ring of the image (SPF) a few values are spilled AROUND the EM loops
+    # (test_scan_em_loops_have_no_scratch_traffic checks that they stay outside)
+    for tmpl, ms, mb in (("<2, 2, 16, 1, false, false, false>", 4, 20), ("<4, 4, 16, 1, false, false, false>", 10, 28)):
+        vgpr, vspill, scratch, occ = get(tmpl)
+        assert occ == 2 and vspill <= ms and scratch <= mb, (tmpl, vgpr, vspill, scratch, occ)
     vgpr, vspill, scratch, occ = get("<4, 8, 16, 1, false, false, false>")      # config 3
     assert occ == 2 and vspill <= 4 and scratch <= 16, (vgpr, vspill, scratch, occ)
     for tmpl in ("<1, 2, 16, 1, false, false, true>", "<4, 8, 16, 1, false, false, true>"):   # FIT forms
         vgpr, vspill, scratch, occ = get(tmpl)
         assert (vspill, scratch, occ) == (0, 0, 2), (tmpl, vgpr, vspill, scratch, occ)
+
+
+def test_scan_em_loops_have_no_scratch_traffic():
+    """The EM loops (dense and masked body) of the short-chunk scan kernels with the read-ahead ring of the
+    series image (SPF, em_scan_impl.h) hold no scratch instruction: what the allocator spills -- none to ten
+    values depending on the shape -- is stored before a loop and reloaded behind it.  ((4,4) at L = 16, the
+    widest shape with the ring at every chunk length, may keep ONE access in its masked loop; and the image reads
+    do run ahead: no s_waitcnt lgkmcnt(0) directly behind a ds_read_b128 in F1 / B2 is what the ring is for,
+    checked on the GPU by the small-launch timings of profiles/r04_small_launches.txt.)"""
+    import subprocess
+    import tempfile
+    import loop_mix
+    csrc = os.path.join(ROOT, "ldsr_amd", "csrc")
+    shapes = [(1, 2, 16, "false", 0), (1, 2, 16, "true", 0), (2, 2, 16, "false", 0), (4, 4, 13, "true", 0),
+              (4, 4, 16, "false", 1), (1, 4, 13, "true", 0)]
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "one.hip")
+        with open(src, "w") as f:
+            f.write('#include "em_scan_impl.h"\n')
+            for pp, qq, L, q, _ in shapes:
+                f.write("template __global__ void em_scan_kernel<%d, %d, %d, 1, %s, false, false>(EmParams);\n" % (pp, qq, L, q))
+        asm = os.path.join(td, "one.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-I" + csrc, "--offload-arch=gfx950",
+                        "--cuda-device-only", "-S", src, "-o", asm], check=True, capture_output=True)
+        found = loop_mix.loops(asm, "em_scan_kernel")
+    for pp, qq, L, q, allowed in shapes:
+        tag = "ILi%dELi%dELi%dELi1ELb%dELb0ELb0EE" % (pp, qq, L, 1 if q == "true" else 0)
+        big = [(hi - lo, c) for name, lo, hi, c, ops, n in found if tag in name and hi - lo >= 1000]
+        assert big, tag
+        assert max(c.get("scratch", 0) for _, c in big) <= allowed, (tag, [(n, c.get("scratch", 0)) for n, c in big])
 
 
 def test_pair_kernel_register_budget():

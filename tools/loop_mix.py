@@ -38,12 +38,11 @@ def classify(op, line):
     return "valu:int/other"
 
 
-def main():
-    path = sys.argv[1]
-    part = sys.argv[2] if len(sys.argv) > 2 else ""
-    floor = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+def loops(path, part=""):
+    """[(function name, first instruction, last instruction, Counter of classes, Counter of opcodes)] of every
+    loop of the functions whose name contains `part`, largest first."""
     lines = open(path).read().split("\n")
-    # functions: "name:" at column 0 up to .Lfunc_end
+    out = []
     i = 0
     while i < len(lines):
         m = re.match(r"^(_Z\w+):", lines[i])
@@ -65,28 +64,40 @@ def main():
             if re.match(r"^_Z\w+:", s):
                 continue
             insts.append(s)
-        loops = []
+        found = []
         for k, s in enumerate(insts):
             op = s.split()[0]
             if op.startswith("s_cbranch") or op == "s_branch":
                 tgt = s.split()[-1]
                 if tgt in labels and labels[tgt] <= k:
-                    loops.append((labels[tgt], k))
-        print("== %s: %d instructions, %d loops" % (name, len(insts), len(loops)))
-        for lo, hi in sorted(set(loops), key=lambda r: r[0] - r[1]):
-            if hi - lo < floor:
-                continue
+                    found.append((labels[tgt], k))
+        for lo, hi in sorted(set(found), key=lambda r: r[0] - r[1]):
             c = collections.Counter()
             ops = collections.Counter()
             for s in insts[lo:hi + 1]:
                 op = s.split()[0]
                 c[classify(op, s)] += 1
                 ops[op + ("_dpp" if "dpp" in s else "")] += 1
-            valu = sum(n for k2, n in c.items() if k2.startswith("valu"))
-            print("  loop @%d..%d: %d instructions, VALU %d" % (lo, hi, hi - lo + 1, valu))
-            for k2, n in sorted(c.items(), key=lambda kv: -kv[1]):
-                print("      %-20s %5d" % (k2, n))
-            print("      top:", ", ".join("%s %d" % kv for kv in ops.most_common(14)))
+            out.append((name, lo, hi, c, ops, len(insts)))
+    return out
+
+
+def main():
+    path = sys.argv[1]
+    part = sys.argv[2] if len(sys.argv) > 2 else ""
+    floor = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    last = None
+    for name, lo, hi, c, ops, n_insts in loops(path, part):
+        if name != last:
+            print("== %s: %d instructions" % (name, n_insts))
+            last = name
+        if hi - lo < floor:
+            continue
+        valu = sum(n for k2, n in c.items() if k2.startswith("valu"))
+        print("  loop @%d..%d: %d instructions, VALU %d" % (lo, hi, hi - lo + 1, valu))
+        for k2, n in sorted(c.items(), key=lambda kv: -kv[1]):
+            print("      %-20s %5d" % (k2, n))
+        print("      top:", ", ".join("%s %d" % kv for kv in ops.most_common(14)))
 
 
 if __name__ == "__main__":
