@@ -62,6 +62,16 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
 #define LDSR_STEADY_MIN_L 24
 #endif
+// read-ahead rings of the generic sweeps (pair_generic_sweeps: SPF): short chunks, narrow inputs
+#ifndef LDSR_PAIR_SPF
+#define LDSR_PAIR_SPF 1
+#endif
+#ifndef LDSR_PAIR_SPF_MAXL
+#define LDSR_PAIR_SPF_MAXL 16
+#endif
+__host__ __device__ constexpr bool pair_spf(int PP, int QQ, int L) {
+    return LDSR_PAIR_SPF && L <= LDSR_PAIR_SPF_MAXL && PP + QQ <= 8;
+}
 // steps of the transient block: L-1 (the chunk of lane 0 without its predicated step)
 __host__ __device__ constexpr int pair_steady_ntr(int L, int LPC) { return L - 1; }
 __host__ __device__ constexpr bool pair_steady(int L, int LPC, int PP, int QQ) {
@@ -99,6 +109,71 @@ __device__ __forceinline__ void rscan_cross(double &P, double &G, double &H, int
     }
 }
 
+// The closed-form lead's passes walk a lane's nj steps of the (whitened) u_t, [step][lane][PP] in LDS.  A rolled
+// loop reads each trip's values and waits for them before it computes: with two waves per SIMD the other wave
+// covers the LDS latency, a lone wave -- the drained tail of a run to convergence, or a reference-sized call --
+// stands still once per trip (config 4's shape, 16 lone cells: 94 cycles per step of the second pass against 58
+// with the SIMD shared).  Here the values of the NEXT four steps are in flight while four steps are computed
+// (two register buffers, the loop unrolled over both: no copies); step(j, u) sees the steps in order, so
+// results are bit-identical.  nA = rows of the lane's column (reads are clamped to it).  Padded p >= 4 keeps the
+// plain loops: with one step per buffer the walk advances by two steps an iteration, the second pass's
+// renormalisation every fourth step is no longer a constant of the unrolled copies, and the (4,4) / (4,8) LEAD
+// kernels lose 45..50 % (same box: T = 813 (3,3) 8192 cells 1.55 -> 2.24 ms).
+#ifndef LDSR_LEAD_PIPE
+#define LDSR_LEAD_PIPE 1
+#endif
+#ifndef LDSR_LEAD_PIPE_MAXP
+#define LDSR_LEAD_PIPE_MAXP 2
+#endif
+__host__ __device__ constexpr bool lead_pipe(int PP) { return LDSR_LEAD_PIPE && PP <= LDSR_LEAD_PIPE_MAXP; }
+template <int PP, int LPC, typename F>
+__device__ __forceinline__ void lead_walk(const double *lup, int nj, int nA, F &&step) {
+    constexpr int G = PP >= 4 ? 1 : 4 / PP;              // steps per buffer: four doubles in flight per buffer (G >= 2: see lead_pipe)
+    constexpr long ROW = (long)LPC * PP;                 // doubles between two steps of a lane
+    double ua[G][PP], ub[G][PP];
+    // rows r0 .. r0+G-1 at immediate offsets from a running pointer (main loop: all of them exist) ...
+    auto rd = [&](const double *base, double (&w)[G][PP]) {
+#pragma unroll
+        for (int i = 0; i < G; i++)
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) w[i][p_] = base[i * ROW + p_];
+    };
+    // ... or clamped to the lane's last row (head and tail of the walk)
+    auto rdc = [&](int j0, double (&w)[G][PP]) {
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int jj = min(j0 + i, nA - 1);
+#pragma unroll
+            for (int p_ = 0; p_ < PP; p_++) w[i][p_] = lup[jj * ROW + p_];
+        }
+    };
+    if (nj <= 0) return;
+    int j0 = 0;
+    rdc(0, ua);
+    const double *base = lup;
+    for (; j0 + 3 * G <= nj; j0 += 2 * G, base += 2 * G * ROW) {
+        rd(base + G * ROW, ub);
+#pragma unroll
+        for (int i = 0; i < G; i++) step(j0 + i, ua[i]);
+        rd(base + 2 * G * ROW, ua);
+#pragma unroll
+        for (int i = 0; i < G; i++) step(j0 + G + i, ub[i]);
+    }
+    // fewer than 3 G steps left: ua holds the first G of them
+    double uc[G][PP];
+    rdc(j0 + G, ub);
+    rdc(j0 + 2 * G, uc);
+#pragma unroll
+    for (int i = 0; i < G; i++)
+        if (j0 + i < nj) step(j0 + i, ua[i]);
+#pragma unroll
+    for (int i = 0; i < G; i++)
+        if (j0 + G + i < nj) step(j0 + G + i, ub[i]);
+#pragma unroll
+    for (int i = 0; i < G; i++)
+        if (j0 + 2 * G + i < nj) step(j0 + 2 * G + i, uc[i]);
+}
+
 // Sums and likelihood terms of one E-step, as the sweeps leave them in every lane (reduced over the
 // cell's lanes afterwards by em_pair_body)
 template <int PP, int QQ>
@@ -122,6 +197,26 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     auto Yat = [&](int j) { return val(j, 0); };
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
+    // SPF (em_scan_impl.h scan_spf): short chunks read the image a step or two ahead of its use through a register
+    // ring, and B2's first pass the h_t strip -- a lone wave (the drained tail of a run to convergence) otherwise
+    // stands still for the LDS latency at every read
+    constexpr bool SPF = pair_spf(PP, QQ, L);
+    constexpr int SPFD = scan_pairs(PP, QQ) <= 2 ? 2 : 1;
+    constexpr int SPFN = SPFD + 1;
+    constexpr int KH2 = 2 * (KV / 2);
+    constexpr bool KODD = (KV & 1) != 0;
+    struct StepRing {
+        double w[SPFN][KH2 > 0 ? KH2 : 1];
+        double o[2][2];
+    };
+    auto ring_rd = [&](double (&w)[KH2 > 0 ? KH2 : 1], double (&o)[2][2], int jn, bool with_odd) {
+#pragma unroll
+        for (int i = 0; i < KH2; i++) w[i] = val(jn, i);
+        if (KODD && with_odd) {
+            o[(jn >> 1) & 1][0] = val(jn & ~1, KV - 1);
+            o[(jn >> 1) & 1][1] = val(jn | 1, KV - 1);
+        }
+    };
     const bool act = vl < nl, tail = vl < rp;
     const int lastLane = nl - 1;
     const double A = th.A, C = th.C, Q = th.Q, R = th.R;
@@ -138,6 +233,20 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
         double bu = 0.0;
 #pragma unroll
         for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], Uat(j, p_), bu);
+        return bu;
+    };
+    auto e_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
+        auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+        double e = vv(0);
+#pragma unroll
+        for (int q_ = 0; q_ < QQ; q_++) e = fma(-th.D[q_], vv(1 + PP + q_), e);
+        return e;
+    };
+    auto bu_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
+        auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+        double bu = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], vv(1 + p_), bu);
         return bu;
     };
     double Jv[L], gv_[L];
@@ -194,8 +303,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
         const double r10 = fma(q10, al_, q11 * C2R_), r11 = fma(q10, Q_, q11 * c);
         if (act) {
             double ra = 0.0, rb = 0.0, rcc = c;
-            auto row = [&](int j) {
-                const double e = e_at(j), bu = bu_at(j);
+            auto row_c = [&](int j, double e, double bu) {
                 gv_[j] = e; Jv[j] = bu;
                 const double s20 = fma(bu, C2R, ACR * e);
                 const double na = fma(ra, al_, fma(rb, C2R_, rcc * s20));
@@ -203,18 +311,32 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
                 ra = na;
                 rcc *= A_;
             };
-            if (tail) row(L - 1);
+            auto row = [&](int j) { row_c(j, e_at(j), bu_at(j)); };
+            if constexpr (SPF) {
+                StepRing r;      // steps L-1 (predicated), L-2, ... 0; step j in slot j % SPFN
 #pragma unroll
-            for (int j = L - 2; j >= 0; j--) row(j);
+                for (int d = 0; d < SPFD; d++)
+                    if (L - 1 - d >= 0) ring_rd(r.w[(L - 1 - d) % SPFN], r.o, L - 1 - d, d == 0 || ((L - 1 - d) & 1) != 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                for (int j = L - 1; j >= 0; j--) {
+                    if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                    if (j < L - 1 || tail) row_c(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            } else {
+                if (tail) row(L - 1);
+#pragma unroll
+                for (int j = L - 2; j >= 0; j--) row(j);
+            }
             M.m00 = tail ? r00 : q00; M.m01 = tail ? r01 : q01;
             M.m10 = tail ? r10 : q10; M.m11 = tail ? r11 : q11;
             M.m20 = ra; M.m21 = rb; M.m22 = rcc * cinv;
             prenorm(M);
         }
     } else if (act) {
-        auto f1 = [&](int j) {
+        auto f1c = [&](int j, double e, double bu) {
             const bool o = (obsmask >> j) & 1u;
-            const double e = e_at(j), bu = bu_at(j);
             gv_[j] = e; Jv[j] = bu;
             const double a00 = o ? alpha : A2;
             const double g = o ? C2R : 0.0;
@@ -226,9 +348,25 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
             }
             if ((j & 15) == 15 && j < L - 2) prenorm(M);
         };
+        auto f1 = [&](int j) { f1c(j, e_at(j), bu_at(j)); };
+        if constexpr (SPF) {
+            StepRing r;
 #pragma unroll
-        for (int j = 0; j < L - 1; j++) f1(j);
-        if (tail) f1(L - 1);
+            for (int d = 0; d < SPFD; d++)
+                if (d <= L - 1) ring_rd(r.w[d % SPFN], r.o, d, (d & 1) == 0);
+            __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+            for (int j = 0; j < L - 1; j++) {
+                if (j + SPFD <= L - 1) ring_rd(r.w[(j + SPFD) % SPFN], r.o, j + SPFD, ((j + SPFD) & 1) == 0);
+                f1c(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                __builtin_amdgcn_sched_barrier(0x6);
+            }
+            if (tail) f1c(L - 1, e_of(r.w[(L - 1) % SPFN], r.o, L - 1), bu_of(r.w[(L - 1) % SPFN], r.o, L - 1));
+        } else {
+#pragma unroll
+            for (int j = 0; j < L - 1; j++) f1(j);
+            if (tail) f1(L - 1);
+        }
         prenorm(M);
     }
 
@@ -340,10 +478,9 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     // the fly (Vs_t is not needed again).  pass 2: the sums over Xs_t (no dependence between
     // steps, the LDS reads of the series batch freely).
     const double XnE = Xn;
-    auto b2a = [&](int j) {
+    auto b2a_h = [&](int j, double h) {
         const bool o = DENSE || ((obsmask >> j) & 1u);
         const double J = Jv[j];
-        const double h = (j < L - 1) ? hs[j * 64] : hlast;
         aTx1x = fma(Vn, J, aTx1x);                  // Vs_{t+1} J_t   (:180; J = 0 at t = T-1)
         const double Xs = fma(J, Xn, gv_[j]);       // :101
         const double Vs = fma(J * J, Vn, h);        // :102
@@ -353,33 +490,65 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
         Xn = Xs;
         Vn = Vs;
     };
-    auto b2b = [&](int j, bool top) {
+    auto b2a = [&](int j) { b2a_h(j, (j < L - 1) ? hs[j * 64] : hlast); };
+    auto b2b_v = [&](int j, bool top, auto &&vv) {
         const bool o = DENSE || ((obsmask >> j) & 1u);
         const double Xs = gv_[j];
         const double Xnx = top ? XnE : gv_[top ? j : j + 1];
         aTx1x = fma(Xnx, Xs, aTx1x);                // :180
 #pragma unroll
         for (int p_ = 0; p_ < PP; p_++) {
-            const double ut = Uat(j, p_);           // zero at t = T-1
+            const double ut = vv(1 + p_);           // zero at t = T-1
             aTx1u[p_] = fma(Xnx, ut, aTx1u[p_]);    // :190
             aTux[p_] = fma(ut, Xs, aTux[p_]);       // :191
         }
         aPall = fma(Xs, Xs, aPall);
         const double xo = o ? Xs : 0.0;
-        aSyx = fma(Yat(j), xo, aSyx);               // :151
+        aSyx = fma(vv(0), xo, aSyx);                // :151
         if (!DENSE) aSxx = fma(xo, xo, aSxx);
 #pragma unroll
-        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, Vat(j, q_), aSxv[q_]);   // :159
-        if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        for (int q_ = 0; q_ < QQ; q_++) aSxv[q_] = fma(xo, vv(1 + PP + q_), aSxv[q_]);   // :159
+        if (!SPF && (j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
     };
+    auto b2b = [&](int j, bool top) { b2b_v(j, top, [&](int k) { return val(j, k); }); };
     if (act) {
-        if (tail) b2a(L - 1);
-        else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
+        if constexpr (SPF) {
+            // pass 1: the strip's h_t two steps ahead; pass 2's first image reads are issued ahead of pass 1
+            StepRing r;
 #pragma unroll
-        for (int j = L - 2; j >= 0; j--) b2a(j);
-        if (tail) b2b(L - 1, true);
+            for (int d = 0; d < SPFD; d++)
+                if (L - 1 - d >= 0) ring_rd(r.w[(L - 1 - d) % SPFN], r.o, L - 1 - d, d == 0 || ((L - 1 - d) & 1) != 0);
+            constexpr int HPF = 2;
+            double hr[HPF + 1];
 #pragma unroll
-        for (int j = L - 2; j >= 0; j--) b2b(j, false);
+            for (int d = 0; d < HPF; d++)
+                if (L - 2 - d >= 0) hr[(L - 2 - d) % (HPF + 1)] = hs[(L - 2 - d) * 64];
+            __builtin_amdgcn_sched_barrier(0x6);
+            if (tail) b2a_h(L - 1, hlast);
+            else gv_[L - 1] = XnE;
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) {
+                if (j - HPF >= 0) hr[(j - HPF) % (HPF + 1)] = hs[(j - HPF) * 64];
+                b2a_h(j, hr[j % (HPF + 1)]);
+                __builtin_amdgcn_sched_barrier(0x6);
+            }
+#pragma unroll
+            for (int j = L - 1; j >= 0; j--) {
+                if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; };
+                if (j == L - 1) { if (tail) b2b_v(L - 1, true, vv); }
+                else b2b_v(j, false, vv);
+                __builtin_amdgcn_sched_barrier(0x6);
+            }
+        } else {
+            if (tail) b2a(L - 1);
+            else gv_[L - 1] = XnE;             // "next" of step L-2 for chunks without the L-th step
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2a(j);
+            if (tail) b2b(L - 1, true);
+#pragma unroll
+            for (int j = L - 2; j >= 0; j--) b2b(j, false);
+        }
     }
     // Xn, Vn = Xs, Vs at the first step of this lane's chunk
     X0v = Xn; V0v = Vn;
@@ -486,7 +655,19 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             double al = 1.0, bl = 0.0, a2l = 1.0, ql = 0.0;
             bool var_closed = false;
             double geo = 0.0, geo2 = 0.0;
-            {
+            if constexpr (lead_pipe(PP)) {
+                lead_walk<PP, LPC>(lup, nj, nA, [&](int, const double (&un)[PP]) {
+                    double bu = 0.0;
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], un[p_], bu);
+                    bl = fma(A, bl, bu);
+                    if constexpr (!LDSR_LEAD_CLOSED_VAR) {
+                        ql = fma(A2, ql, Q);
+                        al *= A;
+                        a2l *= A2;
+                    }
+                });
+            } else {
                 double un[PP];
 #pragma unroll
                 for (int p_ = 0; p_ < PP; p_++) un[p_] = (LPF && nj > 0) ? lup[p_] : 0.0;
@@ -618,23 +799,10 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             for (int i = 0; i < NLS; i++) lS[i] = 0.0;
             double c = __builtin_amdgcn_ldexp(dm, de) * Vl;          // c_t, and c1 = c_{t+1}
             double Xs = fma(c, dlt, Xl);
-            double un2[PP];
-#pragma unroll
-            for (int p_ = 0; p_ < PP; p_++) un2[p_] = (LPF && nj > 0) ? lup[p_] : 0.0;
-            for (int j = 0; j < nj; j++) {
-                double ul[PP];
+            auto lead2 = [&](int j, const double (&ul)[PP]) {
                 double bu = 0.0;
-                if constexpr (!LPF) {
 #pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)j * LPC * PP + p_];
-                }
-#pragma unroll
-                for (int p_ = 0; p_ < PP; p_++) { ul[p_] = un2[p_]; bu = fma(th.B[p_], ul[p_], bu); }
-                if constexpr (LPF) {
-                    const int jn = min(j + 1, nj - 1);
-#pragma unroll
-                    for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)jn * LPC * PP + p_];
-                }
+                for (int p_ = 0; p_ < PP; p_++) bu = fma(th.B[p_], ul[p_], bu);
                 const double Xl1 = fma(A, Xl, bu), Vl1 = fma(A2, Vl, Q);
                 dm *= rA;
                 // (every 4 steps: the compiler unrolls this loop by four, where (j & 3) == 3 is a constant of
@@ -653,6 +821,29 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
                     lS[5 + PP + p_] = fma(ul[p_], Xs, lS[5 + PP + p_]);      // sum u_t Xs_t       (:191)
                 }
                 Xl = Xl1; Vl = Vl1; c = c1; Xs = Xs1;
+            };
+            if constexpr (lead_pipe(PP)) {
+                const int nA = (lead + LPC - 1) / LPC;
+                lead_walk<PP, LPC>(lup, nj, nA, lead2);
+            } else {
+                double un2[PP];
+#pragma unroll
+                for (int p_ = 0; p_ < PP; p_++) un2[p_] = (LPF && nj > 0) ? lup[p_] : 0.0;
+                for (int j = 0; j < nj; j++) {
+                    double ul[PP];
+                    if constexpr (!LPF) {
+#pragma unroll
+                        for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)j * LPC * PP + p_];
+                    }
+#pragma unroll
+                    for (int p_ = 0; p_ < PP; p_++) ul[p_] = un2[p_];
+                    if constexpr (LPF) {
+                        const int jn = min(j + 1, nj - 1);
+#pragma unroll
+                        for (int p_ = 0; p_ < PP; p_++) un2[p_] = lup[(long)jn * LPC * PP + p_];
+                    }
+                    lead2(j, ul);
+                }
             }
             if constexpr (LDSR_LEAD_CLOSED_VAR) {
                 // sum of Vp over the lane's steps from its entry value V_e:  Vp_j = A^(2j) V_e + Q (1 + .. + A^(2(j-1)))

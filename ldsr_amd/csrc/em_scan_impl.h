@@ -542,7 +542,6 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     constexpr int SPFN = SPFD + 1;                 // ring slots: step j is used while steps j+1 .. j+SPFD are in flight
     struct StepRing {
         double w[SPFN][KH2 > 0 ? KH2 : 1];
-        double t[KH2 > 0 ? KH2 : 1];               // the predicated step L-1 (reverse sweeps)
         double o[2][2];
     };
     auto ring_rd = [&](double (&w)[KH2 > 0 ? KH2 : 1], double (&o)[2][2], int jn, bool with_odd) {
@@ -732,22 +731,24 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                     rc *= A;
                 };
                 if constexpr (SPF) {
-                    // steps L-1 (predicated), L-2, ... 0: the reads run SPFD steps ahead
+                    // steps L-1 (predicated), L-2, ... 0: the reads run SPFD steps ahead (step j in slot j % SPFN)
                     StepRing r;
-                    ring_rd(r.t, r.o, L - 1, true);
 #pragma unroll
                     for (int d = 0; d < SPFD; d++)
-                        if (L - 2 - d >= 0) ring_rd(r.w[(L - 2 - d) % SPFN], r.o, L - 2 - d, ((L - 2 - d) & 1) != 0);
+                        if (L - 1 - d >= 0) ring_rd(r.w[(L - 1 - d) % SPFN], r.o, L - 1 - d, d == 0 || ((L - 1 - d) & 1) != 0);
                     __builtin_amdgcn_sched_barrier(0x6);
-                    if (tail) {
-                        const double e = e_of(r.t, r.o, L - 1), bu = bu_of(r.t, r.o, L - 1);
-                        eT = e; buT = bu;
-                        ra = fma(bu, C2R, ACR * e); rb = bu; rc = A;
-                    }
 #pragma unroll
-                    for (int j = L - 2; j >= 0; j--) {
+                    for (int j = L - 1; j >= 0; j--) {
                         if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
-                        row_step(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                        if (j == L - 1) {
+                            if (tail) {
+                                const double e = e_of(r.w[j % SPFN], r.o, j), bu = bu_of(r.w[j % SPFN], r.o, j);
+                                eT = e; buT = bu;
+                                ra = fma(bu, C2R, ACR * e); rb = bu; rc = A;
+                            }
+                        } else {
+                            row_step(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                        }
                         __builtin_amdgcn_sched_barrier(0x6);
                     }
                 } else {
@@ -1073,21 +1074,21 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                 // pass 2 reads the image again, last step first: the first reads are issued ahead of pass 1
                 static_assert(HS == 0, "short chunks only");
                 StepRing r;
-                ring_rd(r.t, r.o, L - 1, true);
 #pragma unroll
                 for (int d = 0; d < SPFD; d++)
-                    if (L - 2 - d >= 0) ring_rd(r.w[(L - 2 - d) % SPFN], r.o, L - 2 - d, ((L - 2 - d) & 1) != 0);
+                    if (L - 1 - d >= 0) ring_rd(r.w[(L - 1 - d) % SPFN], r.o, L - 1 - d, d == 0 || ((L - 1 - d) & 1) != 0);
                 __builtin_amdgcn_sched_barrier(0x6);
                 if (tail) b2a(NS - 1);
                 else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }
 #pragma unroll
                 for (int i = NS - 2; i >= 0; i--) b2a(i);
                 __builtin_amdgcn_sched_barrier(0x6);
-                if (tail) b2b_v(L - 1, NS - 1, true, [&](int k) { return k < KH2 ? r.t[k] : r.o[((L - 1) >> 1) & 1][(L - 1) & 1]; });
 #pragma unroll
-                for (int j = L - 2; j >= 0; j--) {
+                for (int j = L - 1; j >= 0; j--) {
                     if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
-                    b2b_v(j, j, false, [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; });
+                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; };
+                    if (j == L - 1) { if (tail) b2b_v(L - 1, NS - 1, true, vv); }
+                    else b2b_v(j, j, false, vv);
                     __builtin_amdgcn_sched_barrier(0x6);
                 }
             } else {
