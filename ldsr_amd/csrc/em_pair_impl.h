@@ -607,7 +607,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
     double lik = NAN, lik1 = NAN, lik2 = NAN;
     int it = 0;
     int wit = 0;             // wave-uniform iteration count (interrupt poll)
-    int pit = 0;             // ... and the one of the priority check (prio_by_age, em_scan_impl.h)
 #ifdef LDSR_SCAN_TIMING
     unsigned long long tick_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_readcyclecounter();
@@ -928,12 +927,6 @@ __device__ __forceinline__ void em_pair_body(const EmParams &prm, const double *
             abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(prm.abort) : 0);
         if (alive && prm.liks && vl == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
-        if constexpr (QUEUE && LDSR_PRIO_STEP > 0) {
-            // the wave's priority follows its oldest cell (checked every 16 iterations)
-            if (((++pit) & 15) == 0)
-                prio_by_age(__any(alive && it >= 3 * LDSR_PRIO_STEP) ? 3 : __any(alive && it >= 2 * LDSR_PRIO_STEP) ? 2
-                            : __any(alive && it >= LDSR_PRIO_STEP) ? 1 : 0);
-        }
         bool stop = it >= prm.niter || abort_now;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;   // :272
         if (alive && stop) {
@@ -1182,16 +1175,10 @@ __device__ __forceinline__ void pair_steady_finish(const PairEnv &E, PairCarry<P
     }
     SCAN_TICK(8)       // reduction, likelihood
     int abort_now = 0;
-    const int wit_ = ++cs.wit;
-    if (E.abort && (wit_ & 63) == 0)            // src/EM.cpp:261-262 polls too
+    if (E.abort && ((++cs.wit) & 63) == 0)      // src/EM.cpp:261-262 polls too
         abort_now = __builtin_amdgcn_readfirstlane(lane == 0 ? ldsr_poll_abort(E.abort) : 0);
     if (active && E.liks && vl == 0) E.liks[(long)cs.cell * E.niter + cs.it] = cs.lik;
     if (active) cs.it++;
-    if constexpr (QUEUE && LDSR_PRIO_STEP > 0) {
-        if ((wit_ & 15) == 0)                   // the wave's priority follows its oldest cell (prio_by_age, em_scan_impl.h)
-            prio_by_age(__any(cs.alive && cs.it >= 3 * LDSR_PRIO_STEP) ? 3 : __any(cs.alive && cs.it >= 2 * LDSR_PRIO_STEP) ? 2
-                        : __any(cs.alive && cs.it >= LDSR_PRIO_STEP) ? 1 : 0);
-    }
     bool stop = active && cs.it >= E.niter;
     if (active && cs.it >= 3 && fabs(cs.lik - cs.lik1) < E.tol && fabs(cs.lik1 - cs.lik2) < E.tol) stop = true;   // :272
     if (cs.alive && abort_now) stop = true;       // (a waiting cell stops too)
@@ -1651,88 +1638,60 @@ __global__ __launch_bounds__(512) void em_pair_kernel(EmParams prm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr long IMG = pair_image_doubles(L, PP, QQ, LPC);
     const int b = blockIdx.x;
-    int s = prm.blk_series[b];
-    int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
+    const int s = prm.blk_series[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *gimg = prm.img2 + (long)s * prm.img2_stride;
+    for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+    // LEAD: the (whitened) u_t of the all-missing first prm.lead steps, [step of the lane][lane][PP],
+    // behind the strips
     constexpr long STRIP = pair_strip_doubles(L);
     double *lu = smem + IMG + (long)(blockDim.x >> 6) * STRIP;
+    if constexpr (LEAD) {
+        const int n3 = ((prm.lead + LPC - 1) / LPC) * LPC * PP;
+        const double *g3 = prm.img3 + (long)s * prm.img3_stride;
+        for (int i = threadIdx.x; i < n3; i += blockDim.x) lu[i] = g3[i];
+    }
+    // STEADY: the first L-1 steps (lane 0's chunk) once more, one step per lane, zero beyond
     constexpr bool STEADY = !LEAD && pair_steady(L, LPC, PP, QQ);
     const double *tri = lu;
-    // QUEUE (runs to convergence): the workgroup is persistent.  When the queue of its series is empty it moves
-    // on to the next series that still has cells to hand out (series_hop below) and loads that series' image --
-    // the launch holds no more workgroups than the device can keep resident (ldsr_api.hip), so the cells of a
-    // series queue up behind its slots and a series that needs 4x the iterations of another (config 5: 34 k to
-    // 130 k E-steps per series) draws 4x the workgroups in the end.  Until round 4 every series had one slot
-    // per cell and its own workgroups: a workgroup lived as long as the slowest of its 16 / 32 cells, the device
-    // ran three rounds of such workgroups, and config 5 took 7.1 ms to convergence for 4.1 ms worth of iterations.
-    for (;;) {
-        const double *gimg = prm.img2 + (long)s * prm.img2_stride;
-        for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
-        // LEAD: the (whitened) u_t of the all-missing first prm.lead steps, [step of the lane][lane][PP],
-        // behind the strips
-        if constexpr (LEAD) {
-            const int n3 = ((prm.lead + LPC - 1) / LPC) * LPC * PP;
-            const double *g3 = prm.img3 + (long)s * prm.img3_stride;
-            for (int i = threadIdx.x; i < n3; i += blockDim.x) lu[i] = g3[i];
+    if constexpr (STEADY) {
+        constexpr int KP = scan_pairs(PP, QQ);
+        constexpr int NTR = pair_steady_ntr(L, LPC);
+        for (int i = threadIdx.x; i < KP * LPC * 2; i += blockDim.x) {
+            const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;      // step l = step l % L of lane l / L
+            const int vi = 2 * m + c;                                         // (an odd K leaves the last half-pair zero)
+            lu[i] = (l < NTR && vi < img_values(PP, QQ)) ? gimg[img_off(l % L, vi, img_values(PP, QQ), LPC, L) + (l / L) * 2] : 0.0;
         }
-        // STEADY: the first L-1 steps (lane 0's chunk) once more, one step per lane, zero beyond
-        if constexpr (STEADY) {
-            constexpr int KP = scan_pairs(PP, QQ);
-            constexpr int NTR = pair_steady_ntr(L, LPC);
-            for (int i = threadIdx.x; i < KP * LPC * 2; i += blockDim.x) {
-                const int c = i & 1, l = (i >> 1) % LPC, m = (i >> 1) / LPC;      // step l = step l % L of lane l / L
-                const int vi = 2 * m + c;                                         // (an odd K leaves the last half-pair zero)
-                lu[i] = (l < NTR && vi < img_values(PP, QQ)) ? gimg[img_off(l % L, vi, img_values(PP, QQ), LPC, L) + (l / L) * 2] : 0.0;
-            }
+    }
+    __syncthreads();
+    const SeriesConst *sc = prm.sc + s;
+    if (sc->status != 0) {
+        // singular Svv / Tuu: every cell of the block (static) or of the series (queue: block 0
+        // of the series' blocks is enough, the others repeat the same writes) ends with status 2
+        const int P = 6 + prm.p + prm.q;
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            const int cell = c0 + c;
+            for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
+            prm.n_iter[cell] = 0;
+            if (prm.liks && prm.liks_nanfill)
+                for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
+            prm.lik[cell] = NAN;
+            prm.status[cell] = 2;
         }
-        __syncthreads();
-        const SeriesConst *sc = prm.sc + s;
-        if (sc->status != 0) {
-            // singular Svv / Tuu: every cell of the block (static) or of the series (queue: whichever
-            // workgroup gets there marks them and closes the series' queue) ends with status 2
-            const int P = 6 + prm.p + prm.q;
-            for (int c = threadIdx.x; c < nc; c += blockDim.x) {
-                const int cell = c0 + c;
-                for (int k = 0; k < P; k++) prm.theta[(long)cell * P + k] = NAN;
-                prm.n_iter[cell] = 0;
-                if (prm.liks && prm.liks_nanfill)
-                    for (int i = 0; i < prm.niter; i++) prm.liks[(long)cell * prm.niter + i] = NAN;
-                prm.lik[cell] = NAN;
-                prm.status[cell] = 2;
-            }
-            if (QUEUE && threadIdx.x == 0) atomicMax(prm.queue + s, nc);
-        } else if (QUEUE || (64 / LPC) * wave < nc) {     // (static: a wave without cells has nothing to do)
-            double *hs = smem + IMG + (long)wave * STRIP + lane;
-            const bool dense = sc->n_obs == prm.T;
-            if constexpr (LEAD) {
-                em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, s, c0, nc, lane, wave);
-            } else {
-                if (dense) {
-                    if constexpr (STEADY) em_pair_body_steady<PP, QQ, L, QUEUE>(prm, smem, hs, tri, s, c0, nc, lane, wave);
-                    else em_pair_body<PP, QQ, L, LPC, true, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
-                } else {
-                    em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
-                }
-            }
-        }
-        // (members with the steady form stay put: with the loop around them the allocator puts ~170 scratch
-        // accesses into the steady sweeps -- config 2 to convergence 0.44 -> 1.43 ms)
-        if constexpr (!QUEUE || STEADY) {
-            break;
+        return;
+    }
+    if (!QUEUE && (64 / LPC) * wave >= nc) return;    // whole wave leaves; no barrier follows
+    double *hs = smem + IMG + (long)wave * STRIP + lane;
+    const bool dense = sc->n_obs == prm.T;
+    if constexpr (LEAD) {
+        em_pair_body<PP, QQ, L, LPC, false, QUEUE, true>(prm, smem, hs, lu, s, c0, nc, lane, wave);
+    } else {
+        if (dense) {
+            if constexpr (STEADY) em_pair_body_steady<PP, QQ, L, QUEUE>(prm, smem, hs, tri, s, c0, nc, lane, wave);
+            else em_pair_body<PP, QQ, L, LPC, true, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
         } else {
-            if (!prm.ser_off) break;
-            __syncthreads();                           // every wave is done with this series' image
-            // (the series the workgroup moves to travels through the first word of the image it is done with: some
-            // members fill the 160 KiB of a CU to the byte, a static __shared__ word would not fit)
-            volatile int *hop_to = reinterpret_cast<volatile int *>(smem);
-            if (threadIdx.x == 0) *hop_to = (prm.abort && ldsr_poll_abort(prm.abort)) ? -2 : series_hop(prm, s);
-            __syncthreads();
-            s = *hop_to;
-            __syncthreads();                           // (read by everyone before the next image overwrites it)
-            if (s == -2) series_drain_interrupted(prm);     // (marks what every queue still holds)
-            if (s < 0) break;
-            c0 = prm.ser_off[s];
-            nc = prm.ser_off[s + 1] - c0;
+            em_pair_body<PP, QQ, L, LPC, false, QUEUE, false>(prm, smem, hs, lu, s, c0, nc, lane, wave);
         }
     }
 }

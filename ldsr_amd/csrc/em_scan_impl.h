@@ -68,23 +68,6 @@ __device__ __forceinline__ double uniform_d(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// Issue priority by the age of the wave's oldest cell (runs to convergence, src/EM.cpp:272).  The time of a
-// launch whose cells stop at very different iterations -- config 5: 142 on average, 745 at most -- is the chain of
-// its longest cell, and while the launch is still full that cell's wave shares its SIMD: 9.5 us per iteration
-// where a lone wave takes 6.  VALU issue is arbitrated by priority first (MI355X_MICROARCH.md, two waves per
-// SIMD), so a wave whose cell has outlived LDSR_PRIO_STEP, 2x, 3x that many iterations raises its priority to
-// 1, 2, 3 and runs at nearly a lone wave's pace; its SIMD partner -- a younger cell, not on the critical path --
-// takes the left-over slots.  Only WHEN an iteration is computed changes, never what it computes.
-#ifndef LDSR_PRIO_STEP
-#define LDSR_PRIO_STEP 128
-#endif
-__device__ __forceinline__ void prio_by_age(int lvl) {        // lvl: wave-uniform
-    if (lvl >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 // Sum N independent per-lane values over the WIDTH (64 or 32) lanes of a group by recursive
 // halving: in the round with exchange distance D a lane keeps one half of its live values, hands
 // the other half to its partner (lane ^ D) and adds what it receives, so the number of live values
@@ -413,19 +396,6 @@ __device__ __forceinline__ void mark_cell_interrupted(const EmParams &prm, int c
     prm.status[cell] = 3;
 }
 
-// After an interrupt: every thread pulls what the queues of ALL series still hold and marks it (work-queue
-// launches with persistent workgroups: the series a workgroup never got to must not keep stale numbers).
-__device__ __forceinline__ void series_drain_interrupted(const EmParams &prm) {
-    for (int sn = 0; sn < prm.n_series; sn++) {
-        const int c0n = prm.ser_off[sn], ncn = prm.ser_off[sn + 1] - c0n;
-        for (int pulls = 0; pulls <= ncn; pulls++) {
-            const int k = atomicAdd(prm.queue + sn, 1);
-            if (k >= ncn) break;
-            mark_cell_interrupted(prm, c0n + k);
-        }
-    }
-}
-
 // QUEUE = waves pull cells from the per-series work queue (cells converge at different
 // iterations); !QUEUE = wave w of block b owns cell c0 + w (every cell runs exactly niter
 // iterations, i.e. tol == 0: nothing to balance, and the queue loop costs ~6 % in spill code).
@@ -434,91 +404,73 @@ __device__ __forceinline__ void series_drain_interrupted(const EmParams &prm) {
 template <int PP, int QQ, int L, int W, bool QUEUE, bool GIMG, bool FIT>
 __global__ __launch_bounds__(scan_wide(PP, QQ) ? 256 : 512) void em_scan_kernel(EmParams prm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int hop_to;                     // QUEUE: the series the workgroup moves to next (-1: none left)
     constexpr long IMG = scan_image_doubles(L, W, PP, QQ);
     const int b = blockIdx.x;
-    int s = prm.blk_series[b];
-    int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];   // QUEUE: the series' cells; else the block's
+    const int s = prm.blk_series[b];
+    const int c0 = prm.blk_cell0[b], nc = prm.blk_ncell[b];   // QUEUE: the series' cells; else the block's
     const int T = prm.T;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nl = (T + L - 1) / L;          // active virtual lanes
     const int rp = T - nl * (L - 1);         // lanes < rp own L steps, the others L-1
+    const double *gimg = prm.img + (long)s * prm.img_stride;
+    const double *ys;
+    double *xch = nullptr;
+    if constexpr (GIMG) {
+        ys = gimg;
+        if constexpr (W > 1) xch = smem;
+    } else {
+        for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
+        ys = smem;
+        if constexpr (W > 1) xch = smem + IMG;
+        __syncthreads();
+    }
+    // global image: buffer resource over the series image (out-of-range reads return 0)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gimg, 0, (int)(IMG * sizeof(double)), 0x00020000);
+    const bool dense = prm.sc[s].n_obs == T && !FIT && W == 1;   // FIT / multi-wave: generic path only
     // The host's interrupt flag is polled every 64 EM iterations OF THE WAVE GROUP (not of the
     // cell: cells that converge in fewer would never poll); once it is seen, the group computes
     // nothing more and marks whatever the queue still hands it.
     int wit = 0;
     bool aborted = false;
-    // QUEUE: the workgroup is persistent and moves on to the next series with cells left when the queue of
-    // its series is empty (em_pair_impl.h em_pair_kernel has the story; ldsr_api.hip sizes the launch)
-    for (;;) {
-        const double *gimg = prm.img + (long)s * prm.img_stride;
-        const double *ys;
-        double *xch = nullptr;
-        if constexpr (GIMG) {
-            ys = gimg;
-            if constexpr (W > 1) xch = smem;
-        } else {
-            for (int i = threadIdx.x; i < (int)IMG; i += blockDim.x) smem[i] = gimg[i];
-            ys = smem;
-            if constexpr (W > 1) xch = smem + IMG;
-            __syncthreads();
-        }
-        // global image: buffer resource over the series image (out-of-range reads return 0)
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gimg, 0, (int)(IMG * sizeof(double)), 0x00020000);
-        const bool dense = prm.sc[s].n_obs == T && !FIT && W == 1;   // FIT / multi-wave: generic path only
-        if constexpr (W > 1) {
-            // one group: every wave of the workgroup works on the same cell
-            int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
-            if constexpr (!QUEUE) {
-                if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0, lane, wave, nl, rp, wit);
-            } else {
-                for (int pulls = 0; pulls <= nc; pulls++) {
-                    if (threadIdx.x == 0) *qslot = atomicAdd(prm.queue + s, 1);
-                    __syncthreads();
-                    const int k = __builtin_amdgcn_readfirstlane(*(volatile int *)qslot);
-                    __syncthreads();              // everyone has read the slot before the next pull
-                    if (k >= nc) break;
-                    if (aborted) { if (threadIdx.x == 0) mark_cell_interrupted(prm, c0 + k); continue; }
-                    aborted = em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, wave, nl, rp, wit);
-                }
-            }
-        } else if constexpr (!QUEUE) {
-            if (wave >= nc) return;   // whole wave leaves; no barrier follows
-            if (dense)
-                em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
-            else
-                em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
-        } else {
-            // Work queue: every wave pulls cells of this series until the counter passes the
-            // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
-            // instead of idling, which keeps two waves per SIMD busy when iteration counts differ a
-            // lot.  The counter only grows and the loop is bounded, so every wave reaches the exit;
-            // which wave computes a cell does not change its result.
-            for (int pulls = 0; pulls <= nc; pulls++) {
-                int k = 0;
-                if (lane == 0) k = atomicAdd(prm.queue + s, 1);
-                k = __builtin_amdgcn_readfirstlane(k);
-                if (k >= nc) break;
-                if (aborted) { if (lane == 0) mark_cell_interrupted(prm, c0 + k); continue; }
-                if (dense)
-                    aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
-                else
-                    aborted = em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
-            }
-        }
+    if constexpr (W > 1) {
+        // one group: every wave of the workgroup works on the same cell
+        int *qslot = reinterpret_cast<int *>(xch + W * (8 + 4 + XCH_SUMS));
         if constexpr (!QUEUE) {
-            break;
+            if (nc > 0) em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0, lane, wave, nl, rp, wit);
         } else {
-            if (!prm.ser_off) break;
-            __syncthreads();                           // every wave is done with this series (and its LDS image)
-            if (threadIdx.x == 0) hop_to = (prm.abort && ldsr_poll_abort(prm.abort)) ? -2 : series_hop(prm, s);
-            __syncthreads();
-            s = hop_to;
-            if (s == -2) series_drain_interrupted(prm);
-            if (s < 0) break;
-            c0 = prm.ser_off[s];
-            nc = prm.ser_off[s + 1] - c0;
+            for (int pulls = 0; pulls <= nc; pulls++) {
+                if (threadIdx.x == 0) *qslot = atomicAdd(prm.queue + s, 1);
+                __syncthreads();
+                const int k = __builtin_amdgcn_readfirstlane(*(volatile int *)qslot);
+                __syncthreads();              // everyone has read the slot before the next pull
+                if (k >= nc) break;
+                if (aborted) { if (threadIdx.x == 0) mark_cell_interrupted(prm, c0 + k); continue; }
+                aborted = em_scan_cell<PP, QQ, L, W, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, wave, nl, rp, wit);
+            }
+        }
+    } else if constexpr (!QUEUE) {
+        if (wave >= nc) return;   // whole wave leaves; no barrier follows
+        if (dense)
+            em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
+        else
+            em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + wave, lane, 0, nl, rp, wit);
+    } else {
+        // Work queue: every wave pulls cells of this series until the counter passes the
+        // series' range (c0 .. c0+nc).  A wave whose cell converges early takes the next one
+        // instead of idling, which keeps two waves per SIMD busy when iteration counts differ a
+        // lot.  The counter only grows and the loop is bounded, so every wave reaches the exit;
+        // which wave computes a cell does not change its result.
+        for (int pulls = 0; pulls <= nc; pulls++) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(prm.queue + s, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= nc) break;
+            if (aborted) { if (lane == 0) mark_cell_interrupted(prm, c0 + k); continue; }
+            if (dense)
+                aborted = em_scan_cell<PP, QQ, L, 1, true, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
+            else
+                aborted = em_scan_cell<PP, QQ, L, 1, false, FIT, GIMG>(prm, ys, rs, xch, s, c0 + k, lane, 0, nl, rp, wit);
         }
     }
 }
@@ -1284,8 +1236,6 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         }
         if (prm.liks && lane == 0 && wv == 0) prm.liks[(long)cell * prm.niter + it] = lik;
         it++;
-        if (LDSR_PRIO_STEP > 0 && W == 1 && (it & (LDSR_PRIO_STEP - 1)) == 0 && prm.tol > 0.0)
-            prio_by_age(__builtin_amdgcn_readfirstlane(it) / LDSR_PRIO_STEP);
         bool stop = it >= prm.niter || interrupted;
         if (it >= 3 && fabs(lik - lik1) < prm.tol && fabs(lik1 - lik2) < prm.tol) stop = true;  // :272
         if (__builtin_amdgcn_readfirstlane((int)stop)) break;   // theta stays the one that produced this fit
@@ -1299,7 +1249,6 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         for (int k = 0; k < QQ; k++) th.D[k] = uniform_d(th.D[k]);
     }
 
-    if (LDSR_PRIO_STEP > 0 && W == 1 && !FIT && it >= LDSR_PRIO_STEP) __builtin_amdgcn_s_setprio(0);
     if (lane == 0 && wv == 0) {
         if constexpr (!FIT) {
             white_out(th, (SeriesConstK)sc);

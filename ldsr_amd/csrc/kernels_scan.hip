@@ -146,25 +146,6 @@ int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
     return lds8 <= kLdsBytes ? 8 : w;
 }
 
-// Work-queue launches of the members without the steady form: persistent workgroups that move from series to
-// series (em_pair_kernel).  The fewer waves share a workgroup -- and with it one LDS image -- the fewer wait for
-// the slowest cell of the workgroup before it can move on: the smallest workgroup that still leaves a CU its
-// eight waves (every workgroup holds its own copy of the image and of the lead's u_t).  0: the member has the
-// steady form (no hopping; em_pair_waves_per_block applies).
-int em_pair_queue_waves_per_block(int T, int PP, int QQ, int lpc, int lead) {
-    const PairPlan p = pair_plan(T, PP, QQ, lpc, lead > 0);
-    if (!p.ok) return 0;
-    if (lead == 0 && pair_steady(p.L, lpc, PP, QQ)) return 0;
-    static const int wq_env = [] { const char *e = getenv("LDSR_QUEUE_WPB"); return e ? atoi(e) : 0; }();
-    for (int w : {1, 2, 4, 8}) {
-        if (wq_env && w != wq_env) continue;
-        const size_t lds = ((size_t)pair_image_doubles(p.L, PP, QQ, lpc) + (size_t)w * pair_strip_doubles(p.L) +
-                            (lead > 0 ? (size_t)pair_lead_doubles(lead, lpc, PP) : 0)) * sizeof(double);
-        if ((8 / w) * (lds + 1024) <= kLdsBytes) return w;
-    }
-    return em_pair_waves_per_block(T, PP, QQ, lpc, lead);
-}
-
 bool em_pair_supported(int T, int PP, int QQ, int lpc, bool lead_form) { return pair_plan(T, PP, QQ, lpc, lead_form).ok; }
 int em_pair_cells_per_block(int T, int PP, int QQ, int lpc, int lead) { return (64 / lpc) * em_pair_waves_per_block(T, PP, QQ, lpc, lead); }
 void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles, bool lead_form) {
@@ -178,10 +159,10 @@ void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, 
 }
 
 hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue,
-                          hipStream_t stream, int wpb) {
+                          hipStream_t stream) {
     PairPlan p = pair_plan(prm.T - prm.lead, PP, QQ, lpc, prm.lead > 0);     // (LEAD form: the tail's plan)
     if (!p.ok || !prm.img2 || (prm.lead > 0 && !prm.img3)) return hipErrorInvalidValue;
-    p.wpb = wpb > 0 ? wpb : em_pair_waves_per_block(prm.T - prm.lead, PP, QQ, lpc, prm.lead);
+    p.wpb = em_pair_waves_per_block(prm.T - prm.lead, PP, QQ, lpc, prm.lead);
 #define CASE_L(Lv) case Lv: return lpc == 32 ? launch_em_pair_L<Lv, 32>(prm, PP, QQ, n_blocks, p.wpb, queue, stream) \
                                              : launch_em_pair_L<Lv, 16>(prm, PP, QQ, n_blocks, p.wpb, queue, stream);
     switch (p.L) {

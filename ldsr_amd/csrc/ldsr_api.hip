@@ -497,7 +497,7 @@ static WsLayout ws_layout(int n_series, int T, int PP, int QQ, int shared_uv, in
     L.img2 = o; o = align256(o + sizeof(double) * (size_t)L.img2_stride * n_series);
     L.img3 = o; o = align256(o + sizeof(double) * (size_t)L.img3_stride * n_series);
     if (L.img_stride) cpb = std::min(cpb, em_scan_cells_per_block(T, PP, QQ));   // the winners' FIT launch
-    if (PP <= 8 && QQ <= 8 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 2);    // the pair family's smallest workgroup (one wave, two cells)
+    if (PP <= 8 && QQ <= 8 && algo != LDSR_ALGO_SERIAL) cpb = std::min(cpb, 4);    // the pair family's smallest workgroup
     L.max_blocks = n_cells / cpb + n_series + 1;
     // (block table, then the device copy of the cell offsets for series_prep's cell ordering)
     L.blk = o; o = align256(o + sizeof(int) * (3 * (size_t)L.max_blocks + (size_t)n_series + 1));
@@ -848,45 +848,17 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     const bool use_queue = (algo == LDSR_ALGO_SCAN && scan_uses_queue(T, PP, QQ, tol)) ||
                            (cpw && (tol > 0.0 || (lead > 0 && (PP > 4 || QQ > 4))));   // (wide LEAD forms: work-queue schedule only)
     std::vector<int> bs, bc, bn;
-    // Work queue with persistent workgroups: no more than the device keeps resident (eight waves per CU), each
-    // started on the series that holds its share of the cells; a workgroup whose series has no cell left to
-    // hand out moves on to the next one that has (series_hop, ldsr_device.h), so the cells queue up behind the
-    // slots and a slow series draws more workgroups as the fast ones finish.  The pair family runs them as
-    // small as the LDS allows (em_pair_queue_waves_per_block); its members with the steady form, and
-    // LDSR_QUEUE_SLOTS=0 (A/B runs), keep one slot per cell and workgroups bound to their series.
-    static const bool all_slots = [] { const char *e = getenv("LDSR_QUEUE_SLOTS"); return e && e[0] == '0'; }();
-    const int wq = (use_queue && cpw && !all_slots) ? em_pair_queue_waves_per_block(Te, PP, QQ, lpc, lead) : 0;
-    const bool hop = use_queue && !all_slots && (cpw ? wq > 0 : true);
-    if (hop) {
-        const int waves_pb = cpw ? wq : cpb * (T > 4096 ? 4 : T > 2048 ? 2 : 1);
-        const int cpb_q = cpw ? (64 / lpc) * wq : cpb;
-        long needed = 0;
-        for (int s = 0; s < n_series; s++) needed += (cell_offsets[s + 1] - cell_offsets[s] + cpb_q - 1) / cpb_q;
-        const long resident = (long)device_cu_count(device) * std::max(1, 8 / std::max(1, waves_pb));
-        const int nb = (int)std::min(needed, resident);
-        int s = 0;
-        for (int b = 0; b < nb; b++) {
-            const long first = (long)b * n_cells / nb;               // the cell this workgroup's share starts at
-            while (s + 1 < n_series && cell_offsets[s + 1] <= first) s++;
+    for (int s = 0; s < n_series; s++)
+        for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
             bs.push_back(s);
-            bc.push_back(cell_offsets[s]);
-            bn.push_back(cell_offsets[s + 1] - cell_offsets[s]);
-        }
-    } else if (use_queue) {
-        for (int s = 0; s < n_series; s++)
-            for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
-                bs.push_back(s);
+            if (use_queue) {
                 bc.push_back(cell_offsets[s]);
                 bn.push_back(cell_offsets[s + 1] - cell_offsets[s]);
-            }
-    } else {
-        for (int s = 0; s < n_series; s++)
-            for (int c = cell_offsets[s]; c < cell_offsets[s + 1]; c += cpb) {
-                bs.push_back(s);
+            } else {
                 bc.push_back(c);
                 bn.push_back(std::min(cpb, cell_offsets[s + 1] - c));
             }
-    }
+        }
     const int n_blocks = (int)bs.size();
     if (n_blocks > L.max_blocks) return fail(LDSR_EINVAL, "internal: block table overflow");
     std::vector<int> tab;
@@ -899,8 +871,8 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     // series_prep also orders every series' cells by predicted slowness (em_pair_impl.h
     // em_pair_body_steady); it reads the cell offsets from the device copy behind the block table.
     const bool steady_launch = cpw && lpc == 32 && lead == 0 && pair_steady(L.img2_L, 32, PP, QQ) && order_enabled();
-    tab.insert(tab.end(), cell_offsets, cell_offsets + n_series + 1);    // (device copy of the cell offsets)
     if (steady_launch) {
+        tab.insert(tab.end(), cell_offsets, cell_offsets + n_series + 1);
         L.order_on = true;
         L.order_cpb = use_queue ? 0 : cpb;
         L.order_ntr = L.img2_L - 1;
@@ -941,8 +913,6 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
     prm.theta = d_theta; prm.lik = d_lik; prm.liks = d_liks;
     prm.n_iter = d_n_iter; prm.status = d_status;
     prm.queue = (int *)(ws + L.queue);
-    prm.n_series = n_series;
-    prm.ser_off = hop ? d_tab + 3 * n_blocks : nullptr;
     prm.perm = steady_launch ? (const int *)(ws + L.perm) : nullptr;
     prm.scratch = (double *)(ws + L.scratch);
     prm.scratch_stride = L.scratch_stride;
@@ -956,7 +926,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         remember_kernel(device, nm);
     }
     if (cpw)
-        HIPCHK(launch_em_pair(prm, PP, QQ, lpc, n_blocks, use_queue, stream, hop ? wq : 0));
+        HIPCHK(launch_em_pair(prm, PP, QQ, lpc, n_blocks, use_queue, stream));
     else if (algo == LDSR_ALGO_SCAN)
         HIPCHK(launch_em_scan(prm, PP, QQ, n_blocks, use_queue, false, stream));
     else

@@ -315,27 +315,12 @@ struct EmParams {
     const int *abort;        // host-pinned interrupt flag polled every 64 EM iterations, or null
     double *scratch;         // serial kernel: [T][2][scratch_stride]
     long scratch_stride;
-    // work-queue launches: persistent workgroups that move from series to series (series_hop)
-    int n_series;            // series of the launch
-    const int *ser_off;      // [n_series + 1] first cell of every series (device copy), or null: no hopping
     // FIT variant of the scan kernel (one E-step at theta0, the full fit written out)
     double *fitX, *fitY, *fitV, *fitJ;   // [n_cells][T], any may be null
     double *pen;             // lik(stdlik = FALSE) - lambda * ssq  (R/LDS_GA.R:28-44), may be null
     double lambda;
     int stdlik;              // divide lik by n_obs (src/EM.cpp:124)
 };
-
-// Work-queue launches: the next series after `s` (cyclically) whose queue still has cells to hand out, or -1.
-// A series whose queue is exhausted needs no more workgroups: its remaining cells are running elsewhere.
-__device__ __forceinline__ int series_hop(const EmParams &prm, int s) {
-    for (int k = 1; k < prm.n_series; k++) {
-        int sn = s + k;
-        if (sn >= prm.n_series) sn -= prm.n_series;
-        const int handed = __hip_atomic_load(prm.queue + sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (handed < prm.ser_off[sn + 1] - prm.ser_off[sn]) return sn;
-    }
-    return -1;
-}
 
 // One system-scope load of the interrupt flag (pinned host memory written by the waiting host
 // thread): bypasses the GPU caches, costs one PCIe round trip -- hence only every 64 iterations.

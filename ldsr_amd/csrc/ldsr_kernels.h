@@ -89,9 +89,7 @@ bool em_pair_supported(int T, int PP, int QQ, int lpc, bool lead_form = false); 
 int em_pair_cells_per_block(int T, int PP, int QQ, int lpc, int lead = 0);   // T: the steps the sweeps work on
 int em_pair_waves_per_block(int T, int PP, int QQ, int lpc, int lead = 0);
 void em_pair_layout(int T, int PP, int QQ, int lpc, int *L, long *img_doubles, bool lead_form = false);
-int em_pair_queue_waves_per_block(int T, int PP, int QQ, int lpc, int lead = 0);   // persistent work-queue workgroups (0: none)
-hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue, hipStream_t stream,
-                          int wpb = 0);
+hipError_t launch_em_pair(const EmParams &prm, int PP, int QQ, int lpc, int n_blocks, bool queue, hipStream_t stream);
 void em_pair_kernel_name(int T, int PP, int QQ, int lpc, bool queue, char *buf, size_t len, bool lead = false);
 // kernel names as rocprofv3 prints them (ldsr_em_plan)
 void em_scan_kernel_name(int T, int PP, int QQ, bool queue, bool fit, char *buf, size_t len);
