@@ -562,6 +562,12 @@ static bool pair_pays_with_early_stopping(int T, int PP, int QQ) {
     return T <= 416 && em_pair_waves_per_block(T, PP, QQ, 32, 0) == 4;
 }
 
+// Runs to convergence on fully observed series with wide-ish inputs (padded p + q >= 8): since the scan kernel reads its
+// image ahead (round 4) it beats the two-cells-per-wave kernel on long chunks (T = 813 (3,3) 20 000 cells 2.46 against
+// 2.79 ms), and four cells per wave lose to two (T = 260 (4,4) 20 000 cells 1.13 against 0.97): tools/auto_regret.py,
+// profiles/r04_auto_regret.txt.
+static bool conv_wide(double tol, int PP, int QQ) { return tol > 0.0 && PP + QQ >= 8; }
+
 // does the LEAD form at lp lanes per cell fit a CU's LDS: the tail's image, the strips and the lead's u_t
 static bool lead_fits(int T, int tail, int PP, int QQ, int lp) {
     const bool wide = PP > 4 || QQ > 4;
@@ -653,13 +659,14 @@ static int em_plan_impl(int T, int p, int q, int niter, double tol, int algo, ch
     // kernels with tol > 0 when every series is fully observed)
     const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && !fully_observed;
     if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
+    if (was_auto && algo == LDSR_ALGO_PAIR && conv_wide(tol, PP, QQ) && T > 512 && em_scan_supported(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
     if (algo == LDSR_ALGO_SCAN) {
         if (!em_scan_supported(T, PP, QQ)) return -1;
         if (buf && len) em_scan_kernel_name(T, PP, QQ, scan_uses_queue(T, PP, QQ, tol), false, buf, len);
     } else if (algo == LDSR_ALGO_PAIR || algo == LDSR_ALGO_QUAD) {
         // AUTO (a launch that fills the device assumed): four cells per wave where they fit, else two
         int lpc = algo == LDSR_ALGO_QUAD ? 16 : 32;
-        if (was_auto && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+        if (was_auto && !conv_wide(tol, PP, QQ) && em_pair_supported(T, PP, QQ, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
         if (!em_pair_supported(T, PP, QQ, lpc)) return -1;
         if (buf && len) em_pair_kernel_name(T, PP, QQ, lpc, tol > 0.0, buf, len);
     } else if (algo == LDSR_ALGO_SERIAL) {
@@ -746,7 +753,9 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         for (int s = 0; s < pn; s++) wgs += (po[s + 1] - po[s] + c - 1) / c;
         const long cus = device_cu_count(device);
         if (force_fill()) return true;
-        if (!lead_form && em_pair_waves_per_block(Te, PP, QQ, lp, 0) == 4)
+        // (runs to convergence: only up to chunks of 13 steps -- beyond, the scan kernel with its read-ahead wins on
+        // launches of this size: T = 600 (1,2) 2000 cells 0.284 against 0.313 ms, (2,4) 0.384 against 0.512)
+        if (!lead_form && em_pair_waves_per_block(Te, PP, QQ, lp, 0) == 4 && (tol == 0.0 || Te <= 416))
             return wgs * 8 >= (lp == 16 ? 3 : 2) * cus;
         // the closed-form lead skips most of the work, so it pays from ~1536 cells (same box, scan ->
         // LEAD in ms, tools/lead_fill_ab.sh: T = 2000 (1,4) 1536 cells 1.94 -> 1.40, 3072 3.79 -> 1.47;
@@ -797,6 +806,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
         // T = 300 (2,2) +34 %, T = 400 (1,2) +11..33 %; from T = 500 on the scan kernel wins by 5..24 %.)
         const bool masked_conv = was_auto && algo == LDSR_ALGO_PAIR && tol > 0.0 && dense_hint != 1;
         if (masked_conv && !pair_pays_with_early_stopping(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
+        if (was_auto && algo == LDSR_ALGO_PAIR && conv_wide(tol, PP, QQ) && T > 512 && em_scan_supported(T, PP, QQ)) algo = LDSR_ALGO_SCAN;
         // ... and only when its workgroups (one per CU: 16 cells at two cells per wave, 32 at four) fill
         // the device: 512 cells are 32 pair workgroups on 32 of 256 CUs but 128 scan workgroups on 128
         // of them (a quarter of the time).  Four cells per wave where they fit and fill, else two.
@@ -804,7 +814,7 @@ static int em_batch_device_impl(int device, hipStream_t stream, int n_series, in
             // (masked series with early stopping reach this point only as short series: there four
             // cells per wave win once the launch is large -- tools/auto_regret.py, 20 000 cells:
             // T = 260 (4,4) 9.5 -> 7.0 ms, T = 150 (1,2) 2.96 -> 2.74; at 2000 cells two per wave stay ahead)
-            if (fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
+            if (!conv_wide(tol, PP, QQ) && fills(T, 16)) { lpc = 16; algo = LDSR_ALGO_QUAD; }
             else if (fills(T, 32)) lpc = 32;
             else algo = em_scan_supported(T, PP, QQ) ? LDSR_ALGO_SCAN : LDSR_ALGO_SERIAL;
         }

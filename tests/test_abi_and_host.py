@@ -112,7 +112,10 @@ def test_launch_plan_of_every_shape():
     # (short series keep the pair family with early stopping whatever the mask; a launch that fills
     # the device -- what the plan assumes -- gets four cells per wave: tools/auto_regret.py)
     assert plan(400, 1, 2, 1e-5) == (4, "em_pair_kernel<1, 2, 25, 16, true, false>")
-    assert plan(120, 4, 4, 1e-5) == (4, "em_pair_kernel<4, 4, 8, 16, true, false>")
+    # (runs to convergence with padded p + q >= 8 stay at two cells per wave -- four lose, T = 260 (4,4) 20 000 cells
+    # 1.13 against 0.97 ms -- and take the scan kernel beyond T = 512: profiles/r04_auto_regret.txt)
+    assert plan(120, 4, 4, 1e-5) == (3, "em_pair_kernel<4, 4, 4, 32, true, false>")
+    assert plan(120, 4, 4) == (4, "em_pair_kernel<4, 4, 8, 16, false, false>")
     assert plan(417, 1, 2, 1e-5)[0] == 2 and plan(500, 1, 4, 1e-5)[0] == 2
     # ... and when the caller of the device entry says every y_t is observed (lead_steps = -1)
     buf = C.create_string_buffer(160)
