@@ -361,6 +361,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_SCAN_SPF        // short chunks: the image reads of F1 / B2 run a step or two ahead of their use
 #define LDSR_SCAN_SPF 1
 #endif
+#ifndef LDSR_SCAN_SPF_MAXL   // longest chunk with the read-ahead (chunks beyond 16 steps: F2, the re-run of the first half
+#define LDSR_SCAN_SPF_MAXL 32 // and both segments of B2 read through the ring too; LDS images only)
+#endif
 #ifndef LDSR_SCAN_SPF_MAXPQ  // widest padded p + q that takes the read-ahead at every chunk length (register budget: two
 #define LDSR_SCAN_SPF_MAXPQ 8 // waves per SIMD); wider inputs -- the ring is ~50 VGPRs there -- only with chunks of <= 4 steps
 #endif
@@ -371,7 +374,7 @@ __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_
 // 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3: 4015 +
 // 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).
 __host__ __device__ constexpr bool scan_spf(int PP, int QQ, int L, int W) {
-    return LDSR_SCAN_SPF && W == 1 && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= 16 : L <= 4);
+    return LDSR_SCAN_SPF && W == 1 && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= LDSR_SCAN_SPF_MAXL : L <= 4);
 }
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
@@ -866,20 +869,8 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         constexpr bool PF = L > 16 && !EBR && (LDSR_SCAN_PREFETCH || (GIMG && LDSR_GIMG_PREFETCH));
         double e_nx = 0.0, bu_nx = 0.0;
         if (PF && act) { e_nx = e_at(0); bu_nx = bu_at(0); }
-        auto f2 = [&](int j) {
+        auto f2c = [&](int j, double e, double bu) {
             const bool o = DENSE || ((obsmask >> j) & 1u);
-            double e, bu;
-            if constexpr (PF) {
-                e = e_nx; bu = bu_nx;
-                if (j + 1 < L) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
-            } else if (EBA && j < L - 1) {
-                e = gv_[j]; bu = hv[j];                // left there by F1; overwritten below by g_t, h_t
-            } else if (SPF) {
-                e = eT; bu = buT;                      // (the predicated step: kept by F1)
-            } else {
-                e = EBR ? ev[j] : e_at(j);
-                bu = EBR ? buv[j] : bu_at(j);
-            }
             const double r = o ? r0 : 0.0;             // 1/Sigma_t; 0 = "no update" (:82-84)
             const double sl = o ? sg : 1.0;
             sprod *= sl;
@@ -927,10 +918,39 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             if (EBA && LDSR_F2_BARRIER_EVERY > 0 && (j % LDSR_F2_BARRIER_EVERY) == LDSR_F2_BARRIER_EVERY - 1)
                 __builtin_amdgcn_sched_barrier(0);
         };
+        auto f2 = [&](int j) {
+            double e, bu;
+            if constexpr (PF) {
+                e = e_nx; bu = bu_nx;
+                if (j + 1 < L) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
+            } else if (EBA && j < L - 1) {
+                e = gv_[j]; bu = hv[j];                // left there by F1; overwritten below by g_t, h_t
+            } else if (SPF) {
+                e = eT; bu = buT;                      // (the predicated step: kept by F1)
+            } else {
+                e = EBR ? ev[j] : e_at(j);
+                bu = EBR ? buv[j] : bu_at(j);
+            }
+            f2c(j, e, bu);
+        };
         if (act) {
+            if constexpr (SPF && L > 16) {
+                // long chunks: F2 reads the image itself (no hand-over from F1) -- through the ring
+                StepRing r;
 #pragma unroll
-            for (int j = 0; j < L - 1; j++) f2(j);
-            if (tail) f2(L - 1);
+                for (int d = 0; d < SPFD; d++) ring_rd(r.w[d % SPFN], r.o, d, (d & 1) == 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) {
+                    if (j + SPFD <= L - 1) ring_rd(r.w[(j + SPFD) % SPFN], r.o, j + SPFD, ((j + SPFD) & 1) == 0);
+                    f2c(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                }
+                if (tail) f2c(L - 1, e_of(r.w[(L - 1) % SPFN], r.o, L - 1), bu_of(r.w[(L - 1) % SPFN], r.o, L - 1));
+            } else {
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) f2(j);
+                if (tail) f2(L - 1);
+            }
         }
         // Xs^2 + Vs at T-1 (0 in the waves that do not own it)
         double termLast = readlane_d(fma(Xu, Xu, Vu), lastLane);
@@ -1070,7 +1090,25 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         };
         auto b2b = [&](int j, int i, bool top) { b2b_v(j, i, top, [&](int k) { return val(j, k); }); };
         if (act) {
-            if constexpr (SPF) {
+            if constexpr (SPF && HS > 0) {
+                // long chunks, stored half [HS, L): steps L-1 (predicated) .. HS through the ring
+                if (tail) b2a(NS - 1);
+                else { gv_[NS - 1] = XnE; hv[NS - 1] = VnE; }
+#pragma unroll
+                for (int i = NS - 2; i >= 0; i--) b2a(i);
+                StepRing r;
+#pragma unroll
+                for (int d = 0; d < SPFD; d++) ring_rd(r.w[(L - 1 - d) % SPFN], r.o, L - 1 - d, d == 0 || ((L - 1 - d) & 1) != 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                for (int j = L - 1; j >= HS; j--) {
+                    if (j - SPFD >= HS) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; };
+                    if (j == L - 1) { if (tail) b2b_v(L - 1, NS - 1, true, vv); }
+                    else b2b_v(j, j - HS, false, vv);
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            } else if constexpr (SPF) {
                 // pass 2 reads the image again, last step first: the first reads are issued ahead of pass 1
                 static_assert(HS == 0, "short chunks only");
                 StepRing r;
@@ -1106,16 +1144,8 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
             // likelihood terms of these steps were already accumulated in F2
             double Xq = Xp0, Vq = Vp0, sgq = sg0, rq = r00;
             if (PF && act) { e_nx = e_at(0); bu_nx = bu_at(0); }
-            auto f2r = [&](int j) {
+            auto f2rc = [&](int j, double e, double bu) {
                 const bool o = DENSE || ((obsmask >> j) & 1u);
-                double e, bu;
-                if constexpr (PF) {
-                    e = e_nx; bu = bu_nx;
-                    if (j + 1 < HS) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
-                } else {
-                    e = EBR ? ev[j] : e_at(j);
-                    bu = EBR ? buv[j] : bu_at(j);
-                }
                 const double r = o ? rq : 0.0;
                 const double w = Vq * r;
                 const double K = C * w;
@@ -1139,16 +1169,52 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
                 Vq = Vp1;
                 __builtin_amdgcn_sched_barrier(0);   // keep later steps' LDS loads from being hoisted (VGPR pressure)
             };
+            auto f2r = [&](int j) {
+                double e, bu;
+                if constexpr (PF) {
+                    e = e_nx; bu = bu_nx;
+                    if (j + 1 < HS) { e_nx = e_at(j + 1); bu_nx = bu_at(j + 1); }
+                } else {
+                    e = EBR ? ev[j] : e_at(j);
+                    bu = EBR ? buv[j] : bu_at(j);
+                }
+                f2rc(j, e, bu);
+            };
             if (act) {
+                if constexpr (SPF) {
+                    StepRing r;
 #pragma unroll
-                for (int j = 0; j < HS; j++) f2r(j);
+                    for (int d = 0; d < SPFD; d++) ring_rd(r.w[d % SPFN], r.o, d, (d & 1) == 0);
+                    __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                    for (int j = 0; j < HS; j++) {
+                        if (j + SPFD < HS) ring_rd(r.w[(j + SPFD) % SPFN], r.o, j + SPFD, ((j + SPFD) & 1) == 0);
+                        f2rc(j, e_of(r.w[j % SPFN], r.o, j), bu_of(r.w[j % SPFN], r.o, j));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HS; j++) f2r(j);
+                }
                 XnE = Xn;                      // Xs, Vs at step HS: the entry of this segment
                 VnE = Vn;
 #pragma unroll
                 for (int i = HS - 1; i >= 0; i--) b2a(i);
-                b2b(HS - 1, HS - 1, true);
+                if constexpr (SPF) {
+                    StepRing r;
 #pragma unroll
-                for (int i = HS - 2; i >= 0; i--) b2b(i, i, false);
+                    for (int d = 0; d < SPFD; d++) ring_rd(r.w[(HS - 1 - d) % SPFN], r.o, HS - 1 - d, d == 0 || ((HS - 1 - d) & 1) != 0);
+                    __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                    for (int j = HS - 1; j >= 0; j--) {
+                        if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
+                        b2b_v(j, j, j == HS - 1, [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; });
+                        __builtin_amdgcn_sched_barrier(0x6);
+                    }
+                } else {
+                    b2b(HS - 1, HS - 1, true);
+#pragma unroll
+                    for (int i = HS - 2; i >= 0; i--) b2b(i, i, false);
+                }
             }
         }
         const double Xs = Xn, Vs = Vn;         // Xs_t, Vs_t at the first step of the chunk
