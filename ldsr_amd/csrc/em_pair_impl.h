@@ -62,12 +62,12 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_STEADY_MIN_L      // shortest chunk whose L-1 transient steps usually reach the fixed point
 #define LDSR_STEADY_MIN_L 24
 #endif
-// read-ahead rings of the generic sweeps (pair_generic_sweeps: SPF): short chunks, narrow inputs
+// read-ahead rings of the generic sweeps (pair_generic_sweeps: SPF): chunks of up to 23 steps, narrow inputs
 #ifndef LDSR_PAIR_SPF
 #define LDSR_PAIR_SPF 1
 #endif
-#ifndef LDSR_PAIR_SPF_MAXL
-#define LDSR_PAIR_SPF_MAXL 16
+#ifndef LDSR_PAIR_SPF_MAXL      // (chunks of 24+ steps: the members with the steady form, whose allocation is left alone;
+#define LDSR_PAIR_SPF_MAXL 23   //  four cells per wave spill there with the ring)
 #endif
 __host__ __device__ constexpr bool pair_spf(int PP, int QQ, int L) {
     return LDSR_PAIR_SPF && L <= LDSR_PAIR_SPF_MAXL && PP + QQ <= 8;
