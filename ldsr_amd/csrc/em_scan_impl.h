@@ -361,6 +361,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_SCAN_SPF        // short chunks: the image reads of F1 / B2 run a step or two ahead of their use
 #define LDSR_SCAN_SPF 1
 #endif
+#ifndef LDSR_SCAN_SPF_GIMG   // ... and the global image of the multi-wave cells (T > 2048): raw buffer loads, a deeper ring
+#define LDSR_SCAN_SPF_GIMG 1
+#endif
 #ifndef LDSR_SCAN_SPF_MAXL   // longest chunk with the read-ahead (chunks beyond 16 steps: F2, the re-run of the first half
 #define LDSR_SCAN_SPF_MAXL 32 // and both segments of B2 read through the ring too; LDS images only)
 #endif
@@ -374,7 +377,7 @@ __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_
 // 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3: 4015 +
 // 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).
 __host__ __device__ constexpr bool scan_spf(int PP, int QQ, int L, int W) {
-    return LDSR_SCAN_SPF && W == 1 && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= LDSR_SCAN_SPF_MAXL : L <= 4);
+    return LDSR_SCAN_SPF && (W == 1 || LDSR_SCAN_SPF_GIMG) && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= LDSR_SCAN_SPF_MAXL : L <= 4);
 }
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
@@ -538,21 +541,38 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     // SPF: the K values of a step are read SPFD steps ahead of their use into an explicit register ring pinned by
     // scheduling barriers (the full pairs of step j in slot j % SPFD; the odd value of an odd K comes in ONE
     // ds_read_b128 for the two steps 2 jj, 2 jj + 1 that share its pair: slot jj & 1).
-    constexpr bool SPF = scan_spf(PP, QQ, L, W) && !GIMG && !scan_ebr(PP, QQ);
-    constexpr int SPFD = scan_pairs(PP, QQ) <= 2 ? 2 : 1;
+    constexpr bool SPF = scan_spf(PP, QQ, L, W) && (!GIMG || LDSR_SCAN_SPF_GIMG) && !scan_ebr(PP, QQ);
+    // (global image: an L2 round trip is several steps long)
+    constexpr int SPFD = GIMG ? (scan_pairs(PP, QQ) <= 2 ? 3 : 2) : (scan_pairs(PP, QQ) <= 2 ? 2 : 1);
     constexpr int KH2 = 2 * (KV / 2);              // values held in full pairs
     constexpr bool KODD = (KV & 1) != 0;
     constexpr int SPFN = SPFD + 1;                 // ring slots: step j is used while steps j+1 .. j+SPFD are in flight
+    constexpr int OSL = SPFD > 2 ? 4 : 2;          // ... and those of the odd values' pairs (a pair serves two steps)
     struct StepRing {
         double w[SPFN][KH2 > 0 ? KH2 : 1];
-        double o[2][2];
+        double o[OSL][2];
     };
-    auto ring_rd = [&](double (&w)[KH2 > 0 ? KH2 : 1], double (&o)[2][2], int jn, bool with_odd) {
+    auto ring_rd = [&](double (&w)[KH2 > 0 ? KH2 : 1], double (&o)[OSL][2], int jn, bool with_odd) {
+        if constexpr (GIMG) {      // one 16-byte buffer load per pair
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < KH2; i++) w[i] = val(jn, i);
-        if (KODD && with_odd) {
-            o[(jn >> 1) & 1][0] = val(jn & ~1, KV - 1);
-            o[(jn >> 1) & 1][1] = val(jn | 1, KV - 1);
+            for (int m = 0; m < KH2 / 2; m++) {
+                const u32x4_t q4 = __builtin_amdgcn_raw_buffer_load_b128(rs, vl * 16, img_off(jn, 2 * m, KV, NL, L) * 8, 0);
+                w[2 * m] = __hiloint2double((int)q4.y, (int)q4.x);
+                w[2 * m + 1] = __hiloint2double((int)q4.w, (int)q4.z);
+            }
+            if (KODD && with_odd) {
+                const u32x4_t q4 = __builtin_amdgcn_raw_buffer_load_b128(rs, vl * 16, img_off(jn & ~1, KV - 1, KV, NL, L) * 8, 0);
+                o[(jn >> 1) & (OSL - 1)][0] = __hiloint2double((int)q4.y, (int)q4.x);
+                o[(jn >> 1) & (OSL - 1)][1] = __hiloint2double((int)q4.w, (int)q4.z);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KH2; i++) w[i] = val(jn, i);
+            if (KODD && with_odd) {
+                o[(jn >> 1) & (OSL - 1)][0] = val(jn & ~1, KV - 1);
+                o[(jn >> 1) & (OSL - 1)][1] = val(jn | 1, KV - 1);
+            }
         }
     };
     const int T = prm.T;
@@ -654,15 +674,15 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
         };
 
         // ... and the same from a step's values held in registers (SPF): value i of step j
-        auto e_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
-            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+        auto e_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[OSL][2], int j) {
+            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & (OSL - 1)][j & 1]; };
             double e = vv(0);
 #pragma unroll
             for (int k = 0; k < QQ; k++) e = fma(-th.D[k], vv(1 + PP + k), e);
             return e;
         };
-        auto bu_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[2][2], int j) {
-            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & 1][j & 1]; };
+        auto bu_of = [&](const double (&w)[KH2 > 0 ? KH2 : 1], const double (&o)[OSL][2], int j) {
+            auto vv = [&](int i) { return i < KH2 ? w[i] : o[(j >> 1) & (OSL - 1)][j & 1]; };
             double bu = 0.0;
 #pragma unroll
             for (int k = 0; k < PP; k++) bu = fma(th.B[k], vv(1 + k), bu);
@@ -1103,7 +1123,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
                 for (int j = L - 1; j >= HS; j--) {
                     if (j - SPFD >= HS) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
-                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; };
+                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & (OSL - 1)][j & 1]; };
                     if (j == L - 1) { if (tail) b2b_v(L - 1, NS - 1, true, vv); }
                     else b2b_v(j, j - HS, false, vv);
                     __builtin_amdgcn_sched_barrier(0x6);
@@ -1124,7 +1144,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
                 for (int j = L - 1; j >= 0; j--) {
                     if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
-                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; };
+                    auto vv = [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & (OSL - 1)][j & 1]; };
                     if (j == L - 1) { if (tail) b2b_v(L - 1, NS - 1, true, vv); }
                     else b2b_v(j, j, false, vv);
                     __builtin_amdgcn_sched_barrier(0x6);
@@ -1207,7 +1227,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
 #pragma unroll
                     for (int j = HS - 1; j >= 0; j--) {
                         if (j - SPFD >= 0) ring_rd(r.w[(j - SPFD) % SPFN], r.o, j - SPFD, ((j - SPFD) & 1) != 0);
-                        b2b_v(j, j, j == HS - 1, [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & 1][j & 1]; });
+                        b2b_v(j, j, j == HS - 1, [&](int k) { return k < KH2 ? r.w[j % SPFN][k] : r.o[(j >> 1) & (OSL - 1)][j & 1]; });
                         __builtin_amdgcn_sched_barrier(0x6);
                     }
                 } else {
