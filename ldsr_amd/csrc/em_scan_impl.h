@@ -364,6 +364,9 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_SCAN_SPF_GIMG   // ... and the global image of the multi-wave cells (T > 2048): raw buffer loads, a deeper ring
 #define LDSR_SCAN_SPF_GIMG 1
 #endif
+#ifndef LDSR_SCAN_SPF_WIDE_LONG
+#define LDSR_SCAN_SPF_WIDE_LONG 1
+#endif
 #ifndef LDSR_SCAN_SPF_MAXL   // longest chunk with the read-ahead (chunks beyond 16 steps: F2, the re-run of the first half
 #define LDSR_SCAN_SPF_MAXL 32 // and both segments of B2 read through the ring too; LDS images only)
 #endif
@@ -377,7 +380,11 @@ __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_
 // 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3: 4015 +
 // 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).
 __host__ __device__ constexpr bool scan_spf(int PP, int QQ, int L, int W) {
-    return LDSR_SCAN_SPF && (W == 1 || LDSR_SCAN_SPF_GIMG) && (PP + QQ <= LDSR_SCAN_SPF_MAXPQ ? L <= LDSR_SCAN_SPF_MAXL : L <= 4);
+    if (!LDSR_SCAN_SPF) return false;
+    if (PP + QQ <= LDSR_SCAN_SPF_MAXPQ) return (W == 1 || LDSR_SCAN_SPF_GIMG) && L <= LDSR_SCAN_SPF_MAXL;
+    // wide inputs (the ring is 40 .. 60 VGPRs): chunks of <= 4 steps, and the half-stored long chunks that have the room --
+    // one wave per cell, 17 .. 24 steps with padded p + q <= 10, 20 steps up to 12 (tools/resource_usage.py: no spills)
+    return W == 1 && (L <= 4 || (LDSR_SCAN_SPF_WIDE_LONG && ((L > 16 && L <= 24 && PP + QQ <= 10) || (L == 20 && PP + QQ <= 12))));
 }
 __host__ __device__ constexpr bool scan_ebr(int PP, int QQ) { return LDSR_WIDE_EBR && PP + QQ >= 12; }
 __host__ __device__ constexpr bool scan_sb(int PP, int QQ) { return (LDSR_WIDE_SB || LDSR_WIDE_EBR) && PP + QQ >= 12; }
@@ -541,7 +548,7 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     // SPF: the K values of a step are read SPFD steps ahead of their use into an explicit register ring pinned by
     // scheduling barriers (the full pairs of step j in slot j % SPFD; the odd value of an odd K comes in ONE
     // ds_read_b128 for the two steps 2 jj, 2 jj + 1 that share its pair: slot jj & 1).
-    constexpr bool SPF = scan_spf(PP, QQ, L, W) && (!GIMG || LDSR_SCAN_SPF_GIMG) && !scan_ebr(PP, QQ);
+    constexpr bool SPF = scan_spf(PP, QQ, L, W) && (!GIMG || (LDSR_SCAN_SPF_GIMG && PP + QQ <= LDSR_SCAN_SPF_MAXPQ)) && !scan_ebr(PP, QQ);
     // (global image: an L2 round trip is several steps long)
     constexpr int SPFD = GIMG ? (scan_pairs(PP, QQ) <= 2 ? 3 : 2) : (scan_pairs(PP, QQ) <= 2 ? 2 : 1);
     constexpr int KH2 = 2 * (KV / 2);              // values held in full pairs

@@ -104,3 +104,26 @@ def test_lead_walk_remainders(eng, lead, p):
     for n, niter, tol in ((2048, 30, 0.0), (8192, 60, 1e-5)):
         _check(eng, y, u, v, th0[:n], 0, niter, tol, "lead=%d p=%d tol=%g" % (lead, p, tol))
         assert _last_kernel().endswith("true>"), _last_kernel()       # a LEAD form ran
+
+
+# half-stored long chunks (17 .. 32 steps): F1, F2, the first half's re-run and both segments of B2 read through the ring;
+# wide inputs where the registers allow (L = 20: padded p + q <= 12, L = 24: <= 10), the others without it
+@pytest.mark.parametrize("T", [1100, 1280, 1400, 1536, 1700, 1792, 1900, 2048])            # L = 20, 20, 24, 24, 28, 28, 32, 32
+@pytest.mark.parametrize("p,q", [(1, 1), (1, 2), (2, 2), (2, 4), (4, 4), (1, 8), (7, 2), (4, 8)])
+def test_scan_kernel_rings_long_chunks(eng, T, p, q):
+    from ldsr_amd import synth
+    th0 = synth.make_init_packed(p, q, 5, seed=T + p + q)
+    for mask in ("dense", "holes"):
+        y, u, v = _case(T, p, q, 700 + T, mask)
+        _check(eng, y, u, v, th0, SCAN, 25, 1e-5, "scan T=%d (%d,%d) %s" % (T, p, q, mask))
+
+
+# the global image of the multi-wave cells (16-byte buffer loads two or three steps ahead, four slots for the odd values' pairs)
+@pytest.mark.parametrize("T", [2100, 3000, 3585, 4097, 5555, 8192])
+@pytest.mark.parametrize("p,q", [(1, 1), (1, 2), (2, 2), (3, 3)])
+def test_scan_kernel_rings_global_image(eng, T, p, q):
+    from ldsr_amd import synth
+    th0 = synth.make_init_packed(p, q, 3, seed=T + q)
+    for mask in ("dense", "holes"):
+        y, u, v = _case(T, p, q, 800 + T % 97, mask)
+        _check(eng, y, u, v, th0, SCAN, 12, 1e-5, "scan T=%d (%d,%d) %s" % (T, p, q, mask))
