@@ -355,16 +355,16 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #ifndef LDSR_GIMG_PREFETCH   // the same pipeline for the global image (same-box A/B: 2-5 % slower -- off)
 #define LDSR_GIMG_PREFETCH 0
 #endif
-#ifndef LDSR_SCAN_PREFETCH   // one-step software pipeline of the LDS reads in the long-chunk sweeps
-#define LDSR_SCAN_PREFETCH 0  // (same-box A/B on cfg4: 10.72 ms with, 10.40 ms without -- off)
+#ifndef LDSR_SCAN_PREFETCH   // round 2's one-step pipeline of the LDS reads in the long-chunk sweeps (members without the
+#define LDSR_SCAN_PREFETCH 0  // ring below: it issues the next step's reads at the top of a step that then waits for its own -- off)
 #endif
-#ifndef LDSR_SCAN_SPF        // short chunks: the image reads of F1 / B2 run a step or two ahead of their use
+#ifndef LDSR_SCAN_SPF        // the image reads of the sweeps run a step or two ahead of their use (scan_spf below)
 #define LDSR_SCAN_SPF 1
 #endif
 #ifndef LDSR_SCAN_SPF_GIMG   // ... and the global image of the multi-wave cells (T > 2048): raw buffer loads, a deeper ring
 #define LDSR_SCAN_SPF_GIMG 1
 #endif
-#ifndef LDSR_SCAN_SPF_WIDE_LONG
+#ifndef LDSR_SCAN_SPF_WIDE_LONG   // ... and wide inputs in the half-stored chunks of 17 .. 24 steps
 #define LDSR_SCAN_SPF_WIDE_LONG 1
 #endif
 #ifndef LDSR_SCAN_SPF_MAXL   // longest chunk with the read-ahead (chunks beyond 16 steps: F2, the re-run of the first half
@@ -374,11 +374,14 @@ __host__ __device__ constexpr int scan_xch_doubles(int W) { return W > 1 ? W * (
 #define LDSR_SCAN_SPF_MAXPQ 8 // waves per SIMD); wider inputs -- the ring is ~50 VGPRs there -- only with chunks of <= 4 steps
 #endif
 __host__ __device__ constexpr bool scan_wide(int PP, int QQ) { return LDSR_WIDE_OCC1 && PP + QQ >= 12; }
-// Read-ahead of the LDS image in the short-chunk sweeps (em_scan_cell: SPF).  Left alone the scheduler issues
-// every ds_read_b128 right before its use and waits for it: with two waves per SIMD the other wave covers
-// that, a LONE wave -- the reference's own call shape, LDS_reconstruction(num.restarts = 50): 50 waves on
-// 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3: 4015 +
-// 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).
+// Read-ahead of the series image in the sweeps (em_scan_cell: SPF).  Left alone the scheduler issues every
+// ds_read_b128 right before its use and waits for it.  Short chunks (<= 16 steps): with two waves per SIMD the
+// other wave covers that, a LONE wave -- the reference's own call shape, LDS_reconstruction(num.restarts = 50): 50
+// waves on 1024 SIMDs -- stands still for the LDS latency ~55 times in F1 and again in B2 (T = 813, p = q = 3:
+// 4015 + 3121 of 12 908 cycles per iteration for 830 instructions, profiles/r03_scan_sections.txt).  Long chunks
+// (a full scheduling barrier behind every step) and the global image of the multi-wave cells were latency bound
+// with the device full as well: T = 2000 (3,3) -27 %, T = 2049 .. 8192 1.6x .. 2.4x (EXPERIMENTS.md R4.10, R4.15, R4.17).
+// Which members take the ring is a matter of registers (two waves per SIMD, tools/resource_usage.py):
 __host__ __device__ constexpr bool scan_spf(int PP, int QQ, int L, int W) {
     if (!LDSR_SCAN_SPF) return false;
     if (PP + QQ <= LDSR_SCAN_SPF_MAXPQ) return (W == 1 || LDSR_SCAN_SPF_GIMG) && L <= LDSR_SCAN_SPF_MAXL;
@@ -546,8 +549,8 @@ __device__ __forceinline__ bool em_scan_cell(const EmParams &prm, const double *
     auto Uat = [&](int j, int k) { return val(j, 1 + k); };
     auto Vat = [&](int j, int k) { return val(j, 1 + PP + k); };
     // SPF: the K values of a step are read SPFD steps ahead of their use into an explicit register ring pinned by
-    // scheduling barriers (the full pairs of step j in slot j % SPFD; the odd value of an odd K comes in ONE
-    // ds_read_b128 for the two steps 2 jj, 2 jj + 1 that share its pair: slot jj & 1).
+    // scheduling barriers (the full pairs of step j in slot j % SPFN; the odd value of an odd K comes in ONE
+    // 16-byte read for the two steps 2 jj, 2 jj + 1 that share its pair: slot jj % OSL).
     constexpr bool SPF = scan_spf(PP, QQ, L, W) && (!GIMG || (LDSR_SCAN_SPF_GIMG && PP + QQ <= LDSR_SCAN_SPF_MAXPQ)) && !scan_ebr(PP, QQ);
     // (global image: an L2 round trip is several steps long)
     constexpr int SPFD = GIMG ? (scan_pairs(PP, QQ) <= 2 ? 3 : 2) : (scan_pairs(PP, QQ) <= 2 ? 2 : 1);
