@@ -66,11 +66,15 @@ __host__ __device__ constexpr long pair_tri_doubles(int PP, int QQ, int LPC = 32
 #ifndef LDSR_PAIR_SPF
 #define LDSR_PAIR_SPF 1
 #endif
+#ifndef LDSR_QUAD_SPF_LONG
+#define LDSR_QUAD_SPF_LONG 1
+#endif
 #ifndef LDSR_PAIR_SPF_MAXL      // (chunks of 24+ steps: the members with the steady form, whose allocation is left alone;
 #define LDSR_PAIR_SPF_MAXL 23   //  four cells per wave spill there with the ring)
 #endif
-__host__ __device__ constexpr bool pair_spf(int PP, int QQ, int L) {
-    return LDSR_PAIR_SPF && L <= LDSR_PAIR_SPF_MAXL && PP + QQ <= 8;
+__host__ __device__ constexpr bool pair_spf(int PP, int QQ, int L, int LPC = 32) {
+    // (four cells per wave have no steady form: their long chunks take the ring where it fits without spills, p + q <= 4)
+    return LDSR_PAIR_SPF && PP + QQ <= 8 && (L <= LDSR_PAIR_SPF_MAXL || (LDSR_QUAD_SPF_LONG && LPC == 16 && PP + QQ <= 4));
 }
 // steps of the transient block: L-1 (the chunk of lane 0 without its predicated step)
 __host__ __device__ constexpr int pair_steady_ntr(int L, int LPC) { return L - 1; }
@@ -200,7 +204,7 @@ __device__ __forceinline__ void pair_generic_sweeps(PairSweepOut<PP, QQ> &o, con
     // SPF (em_scan_impl.h scan_spf): short chunks read the image a step or two ahead of its use through a register
     // ring, and B2's first pass the h_t strip -- a lone wave (the drained tail of a run to convergence) otherwise
     // stands still for the LDS latency at every read
-    constexpr bool SPF = pair_spf(PP, QQ, L);
+    constexpr bool SPF = pair_spf(PP, QQ, L, LPC) && (L <= LDSR_PAIR_SPF_MAXL || DENSE);   // (long chunks: +1.5 % on masked series, -3 .. -11 % on dense ones)
     constexpr int SPFD = scan_pairs(PP, QQ) <= 2 ? 2 : 1;
     constexpr int SPFN = SPFD + 1;
     constexpr int KH2 = 2 * (KV / 2);
